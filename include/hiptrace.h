@@ -1,0 +1,243 @@
+/* hiptrace.h — C ABI of libhiptrace.so: the per-pixel trace / intersect / shade
+ * loop of the Ivoah/RayTracing renderer, rebuilt for AMD MI355X (gfx950).
+ *
+ * The reference has no FFI of its own; the seam this ABI replaces is the body of
+ *   renderFrame(camera, world, img, samples, update, finish, shouldBreak)
+ *   (reference: jvm/src/main/scala/main.scala:73-99)
+ * Everything the JVM host builds before that call (loadScene, main.scala:32-71;
+ * the Camera case class, Camera.scala:3-4; the Hittable / Material / Texture
+ * objects, Hittable.scala, Material.scala, Texture.scala) crosses this boundary
+ * as plain arrays of doubles and ints.  All geometry is passed in fp64, exactly
+ * the values the reference holds; the library does its own conversion.
+ *
+ * Conventions
+ *  - every entry point returns 0 on success or a negative HT_E_* code; a
+ *    human-readable message for the calling thread is in ht_last_error().
+ *  - no C++ exception, abort or exit crosses the boundary.
+ *  - all buffers are caller-allocated and caller-freed; the scene handle owns
+ *    only device memory.
+ *  - one render may be in flight per scene handle; ht_cancel may be called
+ *    from any other thread.
+ *  - the library never falls back to the CPU: without a HIP device every
+ *    compute entry point fails with HT_E_NO_DEVICE.
+ */
+#ifndef HIPTRACE_H
+#define HIPTRACE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HT_VERSION 100 /* 0.1.0 */
+
+/* ---- error codes ------------------------------------------------------- */
+enum {
+  HT_OK = 0,
+  HT_E_INVALID = -1,   /* bad argument / malformed scene description        */
+  HT_E_NO_DEVICE = -2, /* no HIP device, or the requested one does not exist */
+  HT_E_HIP = -3,       /* a HIP runtime call failed                          */
+  HT_E_TOO_LARGE = -4, /* scene does not fit the on-chip scene store         */
+  HT_E_CANCELLED = -5  /* ht_cancel() was observed between sample batches    */
+};
+
+/* ---- primitive / material / texture type tags --------------------------- */
+/* Primitive kinds (reference: Hittable.scala:25-115). */
+enum {
+  HT_PRIM_SPHERE = 0,   /* data: cx cy cz radius                    Hittable.scala:25 */
+  HT_PRIM_XYRECT = 1,   /* data: x0 x1 y0 y1 z                      Hittable.scala:54 */
+  HT_PRIM_XZRECT = 2,   /* data: x0 x1 z0 z1 y                      Hittable.scala:68 */
+  HT_PRIM_YZRECT = 3,   /* data: y0 y1 z0 z1 x                      Hittable.scala:82 */
+  HT_PRIM_TRIANGLE = 4  /* data: ax ay az bx by bz cx cy cz         Hittable.scala:96 */
+};
+#define HT_PRIM_STRIDE 9 /* doubles per primitive in ht_scene_desc.prim_data */
+
+/* Material kinds (reference: Material.scala:9-55). */
+enum {
+  HT_MAT_DIFFUSE = 0,  /* param unused            Material.scala:9  */
+  HT_MAT_GLOSSY = 1,   /* param = roughness       Material.scala:15 */
+  HT_MAT_GLASS = 2,    /* param = ior             Material.scala:23 */
+  HT_MAT_EMISSION = 3  /* param = strength        Material.scala:52 */
+};
+
+/* Texture kinds (reference: Texture.scala:12-107).  Textures form a forest:
+ * a Checker names two child textures by index. */
+enum {
+  HT_TEX_SOLID = 0,   /* data: r g b -          Texture.scala:12 */
+  HT_TEX_CHECKER = 1, /* data: size - - - ; child = {t1, t2}   Texture.scala:20 */
+  HT_TEX_PERLIN = 2,  /* data: scale - - - ; child = {perlin table index, -}  Texture.scala:35 */
+  HT_TEX_IMAGE = 3    /* child = {image index, -}  Texture.scala:97 */
+};
+#define HT_TEX_STRIDE 4 /* doubles per texture in ht_scene_desc.tex_data */
+#define HT_PERLIN_POINTS 256 /* Texture.scala:36 */
+
+/* ---- scene description -------------------------------------------------- */
+/* The flattened world.  Primitive i of prim_* is "primitive id i" everywhere in
+ * this ABI: JSON `world` array order, an STL entry expanded to its facets in
+ * file order (JsonFormats.scala:87-99, BVH.scala:35-55). */
+typedef struct ht_scene_desc {
+  int32_t n_prims;
+  const int32_t* prim_type;     /* [n_prims] HT_PRIM_*                                   */
+  const int32_t* prim_material; /* [n_prims] index into mat_*                            */
+  const double* prim_data;      /* [n_prims * HT_PRIM_STRIDE]                            */
+  const int32_t* prim_group;    /* [n_prims] or NULL: index of the `world` array entry the
+                                   primitive came from.  Informational (the reference nests
+                                   an STL's own BVH as one world entry, main.scala:60); the
+                                   closest hit does not depend on it.                   */
+
+  int32_t n_materials;
+  const int32_t* mat_type;    /* [n_materials] HT_MAT_*            */
+  const int32_t* mat_texture; /* [n_materials] index into tex_*    */
+  const double* mat_param;    /* [n_materials]                     */
+
+  int32_t n_textures;
+  const int32_t* tex_type;  /* [n_textures] HT_TEX_*               */
+  const double* tex_data;   /* [n_textures * HT_TEX_STRIDE]        */
+  const int32_t* tex_child; /* [n_textures * 2]                    */
+
+  /* Decoded images, as BufferedImage.getRGB delivers them to Vec3.fromRGB
+   * (jvm/src/main/scala/FileLoader.scala:14-17, Vec3.scala:36-40):
+   * one 0x00RRGGBB word per texel, row 0 = top of the picture. */
+  int32_t n_images;
+  const int32_t* image_width;   /* [n_images] */
+  const int32_t* image_height;  /* [n_images] */
+  const int64_t* image_offset;  /* [n_images] first texel of image k in image_texels */
+  const uint32_t* image_texels;
+
+  /* Perlin tables (Texture.scala:38-42).  The reference draws them from an
+   * unseeded RNG at load time, so the host passes the ones it drew. */
+  int32_t n_perlin;
+  const double* perlin_ranvec; /* [n_perlin * 256 * 3] unit vectors           */
+  const int32_t* perlin_perm;  /* [n_perlin * 3 * 256] perm_x, perm_y, perm_z */
+} ht_scene_desc;
+
+/* The eight fields of the reference's Camera case class (Camera.scala:3-4,
+ * JsonFormats.scala:10).  The derived basis (Camera.scala:5-17) is computed by
+ * the library. */
+typedef struct ht_camera {
+  double origin[3];
+  double target[3];
+  double vup[3];
+  double vfov;           /* degrees */
+  double aspect_ratio;   /* from the scene file, NOT width/height */
+  double aperture;
+  double focus_distance; /* < 0: |target - origin| */
+  double background[3];
+} ht_camera;
+
+/* ---- render parameters --------------------------------------------------- */
+enum { HT_PRECISION_FP32 = 0, HT_PRECISION_FP64 = 1 };
+
+typedef struct ht_render_params {
+  int32_t width;          /* img.getWidth()   main.scala:81 */
+  int32_t height;         /* img.getHeight()  main.scala:79 */
+  int32_t samples;        /* camera paths per pixel rendered by THIS call          */
+  int32_t sample_offset;  /* global index of this call's first sample: a node that
+                             shards spp over G devices gives rank g the range
+                             [g*spp/G, (g+1)*spp/G) so the sample set is the same
+                             for every G                                           */
+  int32_t max_depth;      /* 50 in the reference (Camera.scala:25); 0 -> 50        */
+  int32_t jitter;         /* 1: sub-pixel jitter + lens sampling as main.scala:88-89,
+                             Camera.scala:20.  0: pixel offset 0.5, aperture 0     */
+  int32_t precision;      /* HT_PRECISION_*: arithmetic type of the device path    */
+  int32_t batch;          /* samples per kernel launch (cancel granularity); 0 -> default */
+  uint64_t seed;          /* Philox key                                             */
+  int32_t device;         /* HIP device ordinal; -1 -> current device              */
+  int32_t collect_counters; /* 1: run the instrumented kernel and fill ht_stats.n_* */
+} ht_render_params;
+
+/* Work counters (per call; n_* only when collect_counters = 1). */
+typedef struct ht_stats {
+  double seconds_total;   /* wall time of the call                                 */
+  double seconds_kernel;  /* device time of the path-tracing launches (HIP events) */
+  int64_t samples;        /* width*height*samples                                   */
+  int32_t launches;       /* path-tracing kernel launches                           */
+  int32_t reserved;
+  int64_t n_rays;         /* rays traced (camera + scattered)                       */
+  int64_t n_box;          /* ray / AABB slab tests                                  */
+  int64_t n_sphere;       /* ray / sphere tests                                     */
+  int64_t n_rect;         /* ray / rect tests                                       */
+  int64_t n_tri;          /* ray / triangle tests                                   */
+  int64_t n_shade[4];     /* scatter evaluations per HT_MAT_*                       */
+  int64_t n_tex[4];       /* texture evaluations per HT_TEX_* (leaf or checker)     */
+  int64_t n_steps;        /* wave-loop iterations x 64 (lane slots offered)         */
+  int64_t n_active;       /* lane slots that held a live path                       */
+} ht_stats;
+
+typedef struct ht_scene ht_scene; /* opaque */
+
+/* ---- entry points -------------------------------------------------------- */
+
+/* Library version (HT_VERSION). */
+int ht_version(void);
+
+/* Number of HIP devices visible to the process (0 when there is none). */
+int ht_device_count(void);
+
+/* Flatten `desc` into device buffers on `device` (-1: current) and build the
+ * BVH.  Replaces the object graph loadScene hands to renderFrame
+ * (main.scala:57-60, BVH.scala:18-33).  The arrays in `desc` are copied. */
+int ht_scene_create(const ht_scene_desc* desc, int device, ht_scene** out);
+void ht_scene_destroy(ht_scene* scene);
+
+/* Render `params->samples` paths per pixel and write the picture.
+ * Replaces the loop main.scala:79-94.
+ *   rgb_linear   [width*height*3] mean linear radiance, row 0 = j = 0 = BOTTOM
+ *                row of the picture (the reference's loop order); may be NULL.
+ *   rgb_packed   [width*height] 0x00RRGGBB after Vec3.toRGB (Vec3.scala:82-84),
+ *                row 0 = TOP, i.e. what img.setRGB(i, H-j-1, ..) leaves in a
+ *                TYPE_INT_RGB BufferedImage (main.scala:93); may be NULL.
+ * Both are host pointers. */
+int ht_render(ht_scene* scene, const ht_camera* camera, const ht_render_params* params,
+              float* rgb_linear, uint32_t* rgb_packed, ht_stats* stats_out);
+
+/* Multi-device building block: add this call's radiance SUMS (not means) into
+ * `accum_dev`, a DEVICE buffer of width*height*3 floats on the scene's device
+ * (row 0 = bottom).  `stream` is a hipStream_t (NULL: default stream).  The call
+ * returns after the work is enqueued and, if stats_out is non-NULL, complete.
+ * The caller reduces the buffers of all ranks (RCCL reduce over xGMI) and then
+ * calls ht_resolve on the root. */
+int ht_render_accumulate(ht_scene* scene, const ht_camera* camera,
+                         const ht_render_params* params, float* accum_dev, void* stream,
+                         ht_stats* stats_out);
+
+/* Divide a DEVICE sum buffer by total_samples and write the host pictures as
+ * ht_render does (mean, then Vec3.toRGB + row flip). */
+int ht_resolve(ht_scene* scene, const float* accum_dev, int32_t width, int32_t height,
+               int64_t total_samples, float* rgb_linear, uint32_t* rgb_packed, void* stream);
+
+/* First-hit buffers with jitter off (u = (i+0.5)/(W-1), v = (j+0.5)/(H-1),
+ * aperture forced to 0): what world.hit(ray, 0.001, +inf) returns for the
+ * camera ray of every pixel (Camera.scala:28, BVH.scala:7-14).
+ *   t        [W*H]   ray parameter of the hit (+inf on a miss)
+ *   prim_id  [W*H]   flattened primitive id (-1 on a miss)
+ *   normal   [W*H*3] Hit.normal (Hittable.scala:7): the primitive's outward
+ *                    normal, flipped to face the ray, NOT normalised
+ * Row 0 = j = 0 = bottom.  `precision` as in ht_render_params.  In fp64
+ * precision the library converts to the float buffers at the end; t64/normal64
+ * (may be NULL) receive the unrounded values. */
+int ht_first_hit(ht_scene* scene, const ht_camera* camera, int32_t width, int32_t height,
+                 int32_t precision, float* t, int32_t* prim_id, float* normal,
+                 double* t64, double* normal64);
+
+/* Ask a running ht_render / ht_render_accumulate on `scene` to stop at the next
+ * sample-batch boundary (the analogue of shouldBreak(), main.scala:80). */
+int ht_cancel(ht_scene* scene);
+
+/* Message for the last failed call on the calling thread ("" if none). */
+const char* ht_last_error(void);
+
+/* Introspection used by tests and the benchmark: sizes of the flattened scene
+ * (nodes of the library's own BVH, bytes of the on-chip scene image, depth). */
+typedef struct ht_scene_info {
+  int32_t n_prims, n_nodes, bvh_depth, n_materials, n_textures;
+  int32_t lds_bytes_fp32, lds_bytes_fp64;
+  int32_t device;
+} ht_scene_info;
+int ht_scene_get_info(const ht_scene* scene, ht_scene_info* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPTRACE_H */
