@@ -207,6 +207,13 @@ int ht_render_accumulate(ht_scene* scene, const ht_camera* camera,
 int ht_resolve(ht_scene* scene, const float* accum_dev, int32_t width, int32_t height,
                int64_t total_samples, float* rgb_linear, uint32_t* rgb_packed, void* stream);
 
+/* As ht_resolve, but the two pictures are DEVICE buffers on the scene's device and
+ * the call only enqueues work on `stream` (no allocation, no host copy): for
+ * callers that keep the frame on the GPU. */
+int ht_resolve_device(ht_scene* scene, const float* accum_dev, int32_t width, int32_t height,
+                      int64_t total_samples, float* rgb_linear_dev, uint32_t* rgb_packed_dev,
+                      void* stream);
+
 /* First-hit buffers with jitter off (u = (i+0.5)/(W-1), v = (j+0.5)/(H-1),
  * aperture forced to 0): what world.hit(ray, 0.001, +inf) returns for the
  * camera ray of every pixel (Camera.scala:28, BVH.scala:7-14).
@@ -236,6 +243,13 @@ typedef struct ht_scene_info {
   int32_t device;
 } ht_scene_info;
 int ht_scene_get_info(const ht_scene* scene, ht_scene_info* out);
+
+/* Process-wide tuning knobs of the device path (no counterpart in the reference):
+ *   "wait_threshold"    lanes of a wave that may wait for shading before
+ *                       traversal yields (1..64)
+ *   "max_blocks_per_cu" cap on resident workgroups per compute unit
+ *   "default_batch"     samples per launch when ht_render_params.batch = 0 */
+int ht_set_option(const char* name, int value);
 
 #ifdef __cplusplus
 }

@@ -123,8 +123,10 @@ EXPORTS = [
     "ht_render",
     "ht_render_accumulate",
     "ht_resolve",
+    "ht_resolve_device",
     "ht_first_hit",
     "ht_cancel",
     "ht_last_error",
     "ht_scene_get_info",
+    "ht_set_option",
 ]

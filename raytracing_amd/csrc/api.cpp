@@ -1,0 +1,499 @@
+// api.cpp — the C ABI of libhiptrace.so (include/hiptrace.h).
+//
+// Replaces the body of renderFrame (reference: jvm/src/main/scala/main.scala:73-99).
+// There is no CPU path in here: without a HIP device every compute entry point
+// fails with HT_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <atomic>
+#include <chrono>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hiptrace.h"
+#include "host_scene.h"
+#include "kernels.h"
+
+using namespace ht;
+
+struct ht_scene {
+  HostScene hs;
+  int device = 0;
+  int n_cu = 0;
+  uint8_t* d_blob32 = nullptr;
+  uint8_t* d_blob64 = nullptr;
+  uint32_t* d_texels = nullptr;
+  uint32_t* d_tile_counter = nullptr;
+  unsigned long long* d_counters = nullptr;
+  std::atomic<int> cancel{0};
+};
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      (void)hipGetLastError();                                                                \
+      return fail(HT_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                  __LINE__);                                                                  \
+    }                                                                                         \
+  } while (0)
+
+// tuning knobs (ht_set_option)
+std::atomic<int> g_wait_threshold{24};
+std::atomic<int> g_max_blocks_per_cu{2};
+std::atomic<int> g_default_batch{64};
+
+// Makes `device` current for the lifetime of the object, then restores.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+    ok = hipSetDevice(device) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+template <typename R>
+void fill_cam(const CameraBasis& b, CamDev<R>& c) {
+  for (int i = 0; i < 3; ++i) {
+    c.origin[i] = (R)b.origin[i];
+    c.llc[i] = (R)b.llc[i];
+    c.horizontal[i] = (R)b.horizontal[i];
+    c.vertical[i] = (R)b.vertical[i];
+    c.u[i] = (R)b.u[i];
+    c.v[i] = (R)b.v[i];
+    c.background[i] = (R)b.background[i];
+  }
+  c.lens_radius = (R)b.lens_radius;
+}
+
+int check_camera(const ht_camera* cam) {
+  if (!cam) return fail(HT_E_INVALID, "camera is NULL");
+  const double* v = cam->origin;
+  for (int i = 0; i < 3; ++i)
+    if (!std::isfinite(v[i]) || !std::isfinite(cam->target[i]) || !std::isfinite(cam->vup[i]))
+      return fail(HT_E_INVALID, "camera has a non-finite field");
+  if (!std::isfinite(cam->vfov) || !std::isfinite(cam->aspect_ratio) || !std::isfinite(cam->aperture))
+    return fail(HT_E_INVALID, "camera has a non-finite field");
+  return HT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ht_version(void) { return HT_VERSION; }
+
+int ht_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+const char* ht_last_error(void) { return g_error.c_str(); }
+
+int ht_set_option(const char* name, int value) {
+  if (!name) return fail(HT_E_INVALID, "option name is NULL");
+  if (!strcmp(name, "wait_threshold")) { g_wait_threshold = std::min(64, std::max(1, value)); return HT_OK; }
+  if (!strcmp(name, "max_blocks_per_cu")) { g_max_blocks_per_cu = std::max(1, value); return HT_OK; }
+  if (!strcmp(name, "default_batch")) { g_default_batch = std::max(1, value); return HT_OK; }
+  return fail(HT_E_INVALID, "unknown option '%s'", name);
+}
+
+void ht_scene_destroy(ht_scene* s) {
+  if (!s) return;
+  {
+    DeviceGuard g(s->device);
+    if (s->d_blob32) (void)hipFree(s->d_blob32);
+    if (s->d_blob64) (void)hipFree(s->d_blob64);
+    if (s->d_texels) (void)hipFree(s->d_texels);
+    if (s->d_tile_counter) (void)hipFree(s->d_tile_counter);
+    if (s->d_counters) (void)hipFree(s->d_counters);
+  }
+  delete s;
+}
+
+int ht_scene_create(const ht_scene_desc* desc, int device, ht_scene** out) {
+  if (!out) return fail(HT_E_INVALID, "out is NULL");
+  *out = nullptr;
+  const int ndev = ht_device_count();
+  if (ndev <= 0) return fail(HT_E_NO_DEVICE, "no HIP device is visible; libhiptrace has no CPU path");
+  if (device < 0) {
+    if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); device = 0; }
+  }
+  if (device >= ndev) return fail(HT_E_NO_DEVICE, "device %d requested, %d visible", device, ndev);
+
+  ht_scene* s = new (std::nothrow) ht_scene;
+  if (!s) return fail(HT_E_INVALID, "out of host memory");
+  std::string err;
+  int rc;
+  try {
+    rc = build_host_scene(desc, s->hs, err);
+  } catch (const std::exception& e) {
+    delete s;
+    return fail(HT_E_INVALID, "scene flattening failed: %s", e.what());
+  }
+  if (rc != HT_OK) {
+    delete s;
+    return fail(rc, "%s", err.c_str());
+  }
+  s->device = device;
+  DeviceGuard g(device);
+  if (!g.ok) { delete s; return fail(HT_E_NO_DEVICE, "cannot select device %d", device); }
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) { delete s; return fail(HT_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); }
+  s->n_cu = prop.multiProcessorCount;
+  const size_t lds_cap = prop.sharedMemPerBlock;  // 160 KiB on gfx950
+  if (lds_bytes_needed(s->hs.layout32, HT_PRECISION_FP32) > lds_cap) {
+    uint32_t need = lds_bytes_needed(s->hs.layout32, HT_PRECISION_FP32);
+    delete s;
+    return fail(HT_E_TOO_LARGE,
+                "scene image + traversal stacks need %u bytes of LDS, the device offers %zu per "
+                "workgroup; scenes beyond the on-chip store are not supported",
+                need, lds_cap);
+  }
+  auto upload = [&](const void* src, size_t bytes, void** dst) -> hipError_t {
+    hipError_t r = hipMalloc(dst, bytes ? bytes : 16);
+    if (r != hipSuccess) return r;
+    if (bytes) r = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    return r;
+  };
+  e = upload(s->hs.blob32.data(), s->hs.blob32.size(), (void**)&s->d_blob32);
+  if (e == hipSuccess) e = upload(s->hs.blob64.data(), s->hs.blob64.size(), (void**)&s->d_blob64);
+  if (e == hipSuccess)
+    e = upload(s->hs.image_texels.data(), s->hs.image_texels.size() * 4, (void**)&s->d_texels);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_tile_counter, 256);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_counters, NUM_COUNTERS * sizeof(unsigned long long));
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    ht_scene_destroy(s);
+    return fail(HT_E_HIP, "device allocation / upload failed: %s", hipGetErrorString(e));
+  }
+  *out = s;
+  return HT_OK;
+}
+
+int ht_scene_get_info(const ht_scene* s, ht_scene_info* out) {
+  if (!s || !out) return fail(HT_E_INVALID, "NULL argument");
+  out->n_prims = (int32_t)s->hs.prim_type.size();
+  out->n_nodes = (int32_t)s->hs.nodes.size();
+  out->bvh_depth = s->hs.depth;
+  out->n_materials = (int32_t)s->hs.mat_type.size();
+  out->n_textures = (int32_t)s->hs.tex_type.size();
+  out->lds_bytes_fp32 = (int32_t)lds_bytes_needed(s->hs.layout32, HT_PRECISION_FP32);
+  out->lds_bytes_fp64 = (int32_t)lds_bytes_needed(s->hs.layout64, HT_PRECISION_FP64);
+  out->device = s->device;
+  return HT_OK;
+}
+
+int ht_cancel(ht_scene* s) {
+  if (!s) return fail(HT_E_INVALID, "scene is NULL");
+  s->cancel.store(1);
+  return HT_OK;
+}
+
+int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_params* p,
+                         float* accum_dev, void* stream_v, ht_stats* stats) {
+  if (!s || !p || !accum_dev) return fail(HT_E_INVALID, "NULL argument");
+  int rc = check_camera(cam);
+  if (rc != HT_OK) return rc;
+  if (p->width < 2 || p->height < 2)
+    return fail(HT_E_INVALID, "width and height must be >= 2 (the reference divides by W-1 and H-1)");
+  if ((int64_t)p->width * p->height > (int64_t)1 << 30) return fail(HT_E_INVALID, "image too large");
+  if (p->samples < 1) return fail(HT_E_INVALID, "samples must be >= 1");
+  if (p->sample_offset < 0) return fail(HT_E_INVALID, "sample_offset must be >= 0");
+  if (p->precision != HT_PRECISION_FP32 && p->precision != HT_PRECISION_FP64)
+    return fail(HT_E_INVALID, "unknown precision %d", p->precision);
+  if (p->device >= 0 && p->device != s->device)
+    return fail(HT_E_INVALID, "scene lives on device %d, params ask for %d", s->device, p->device);
+  const auto t0 = std::chrono::steady_clock::now();
+  hipStream_t stream = (hipStream_t)stream_v;
+  DeviceGuard g(s->device);
+  if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
+
+  const int prec = p->precision;
+  const bool counters = p->collect_counters != 0;
+  const SceneLayout& L = prec == HT_PRECISION_FP32 ? s->hs.layout32 : s->hs.layout64;
+  const uint32_t lds = lds_bytes_needed(L, prec);
+  int bpc = render_blocks_per_cu(prec, counters, lds);
+  if (bpc <= 0)
+    return fail(HT_E_TOO_LARGE, "the render kernel cannot be resident with %u bytes of LDS", lds);
+  bpc = std::min(bpc, g_max_blocks_per_cu.load());
+  const int grid = bpc * s->n_cu;
+
+  CameraBasis basis;
+  camera_basis(*cam, basis);
+  CamDev<float> cam32;
+  CamDev<double> cam64;
+  fill_cam(basis, cam32);
+  fill_cam(basis, cam64);
+  const void* camp = prec == HT_PRECISION_FP32 ? (const void*)&cam32 : (const void*)&cam64;
+
+  RenderArgs a;
+  memset(&a, 0, sizeof a);
+  a.blob = prec == HT_PRECISION_FP32 ? s->d_blob32 : s->d_blob64;
+  a.L = L;
+  a.texels = s->d_texels;
+  a.accum = accum_dev;
+  a.tile_counter = s->d_tile_counter;
+  a.counters = counters ? s->d_counters : nullptr;
+  a.W = p->width;
+  a.H = p->height;
+  a.max_depth = p->max_depth > 0 ? p->max_depth : 50;
+  a.jitter = p->jitter ? 1 : 0;
+  a.seed_lo = (uint32_t)p->seed;
+  a.seed_hi = (uint32_t)(p->seed >> 32);
+  a.wait_threshold = g_wait_threshold.load();
+
+  if (counters) HIP_TRY(hipMemsetAsync(s->d_counters, 0, NUM_COUNTERS * sizeof(unsigned long long), stream));
+
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_batch[2] = {nullptr, nullptr};
+  HIP_TRY(hipEventCreate(&ev_start));
+  HIP_TRY(hipEventCreate(&ev_stop));
+  HIP_TRY(hipEventCreateWithFlags(&ev_batch[0], hipEventDisableTiming));
+  HIP_TRY(hipEventCreateWithFlags(&ev_batch[1], hipEventDisableTiming));
+  auto cleanup = [&]() {
+    (void)hipEventDestroy(ev_start);
+    (void)hipEventDestroy(ev_stop);
+    (void)hipEventDestroy(ev_batch[0]);
+    (void)hipEventDestroy(ev_batch[1]);
+  };
+
+  const int batch = p->batch > 0 ? p->batch : g_default_batch.load();
+  int launches = 0;
+  bool cancelled = false;
+  hipError_t e = hipEventRecord(ev_start, stream);
+  for (int done = 0; e == hipSuccess && done < p->samples; done += batch) {
+    // keep at most two batches in flight so that a cancel request is seen soon
+    if (launches >= 2) e = hipEventSynchronize(ev_batch[launches & 1]);
+    if (e != hipSuccess) break;
+    if (s->cancel.exchange(0)) { cancelled = true; break; }
+    a.sample_first = p->sample_offset + done;
+    a.sample_count = std::min(batch, p->samples - done);
+    e = hipMemsetAsync(s->d_tile_counter, 0, 256, stream);
+    if (e == hipSuccess) e = launch_render(prec, counters, a, camp, grid, lds, stream);
+    if (e == hipSuccess) e = hipEventRecord(ev_batch[launches & 1], stream);
+    launches++;
+  }
+  if (e == hipSuccess) e = hipEventRecord(ev_stop, stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    cleanup();
+    return fail(HT_E_HIP, "render launch failed: %s", hipGetErrorString(e));
+  }
+  if (stats) {
+    memset(stats, 0, sizeof *stats);
+    e = hipEventSynchronize(ev_stop);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev_start, ev_stop);
+    if (e == hipSuccess && counters) {
+      unsigned long long h[NUM_COUNTERS];
+      e = hipMemcpy(h, s->d_counters, sizeof h, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) {
+        stats->n_rays = (int64_t)h[CTR_RAYS];
+        stats->n_box = (int64_t)h[CTR_BOX];
+        stats->n_sphere = (int64_t)h[CTR_SPHERE];
+        stats->n_rect = (int64_t)h[CTR_RECT];
+        stats->n_tri = (int64_t)h[CTR_TRI];
+        for (int k = 0; k < 4; ++k) {
+          stats->n_shade[k] = (int64_t)h[CTR_SHADE0 + k];
+          stats->n_tex[k] = (int64_t)h[CTR_TEX0 + k];
+        }
+        stats->n_steps = (int64_t)h[CTR_STEPS];
+        stats->n_active = (int64_t)h[CTR_ACTIVE];
+      }
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      cleanup();
+      return fail(HT_E_HIP, "render failed on the device: %s", hipGetErrorString(e));
+    }
+    stats->seconds_kernel = ms * 1e-3;
+    stats->launches = launches;
+    stats->samples = (int64_t)p->width * p->height * (cancelled ? (int64_t)(launches)*batch : p->samples);
+    stats->seconds_total =
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  cleanup();
+  if (cancelled) return fail(HT_E_CANCELLED, "render cancelled after %d batches", launches);
+  return HT_OK;
+}
+
+int ht_resolve_device(ht_scene* s, const float* accum_dev, int32_t W, int32_t H, int64_t total_samples,
+                      float* rgb_linear_dev, uint32_t* rgb_packed_dev, void* stream_v) {
+  if (!s || !accum_dev) return fail(HT_E_INVALID, "NULL argument");
+  if (W < 1 || H < 1 || total_samples < 1) return fail(HT_E_INVALID, "bad resolve dimensions");
+  DeviceGuard g(s->device);
+  if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
+  HIP_TRY(launch_resolve(accum_dev, W, H, (float)(1.0 / (double)total_samples), rgb_linear_dev,
+                         rgb_packed_dev, (hipStream_t)stream_v));
+  return HT_OK;
+}
+
+int ht_resolve(ht_scene* s, const float* accum_dev, int32_t W, int32_t H, int64_t total_samples,
+               float* rgb_linear, uint32_t* rgb_packed, void* stream_v) {
+  if (!s || !accum_dev) return fail(HT_E_INVALID, "NULL argument");
+  if (W < 1 || H < 1 || total_samples < 1) return fail(HT_E_INVALID, "bad resolve dimensions");
+  hipStream_t stream = (hipStream_t)stream_v;
+  DeviceGuard g(s->device);
+  if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
+  const size_t n = (size_t)W * H;
+  float* d_mean = nullptr;
+  uint32_t* d_packed = nullptr;
+  if (rgb_linear) HIP_TRY(hipMalloc((void**)&d_mean, n * 3 * sizeof(float)));
+  if (rgb_packed) {
+    hipError_t e = hipMalloc((void**)&d_packed, n * sizeof(uint32_t));
+    if (e != hipSuccess) {
+      if (d_mean) (void)hipFree(d_mean);
+      return fail(HT_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+  }
+  hipError_t e = launch_resolve(accum_dev, W, H, (float)(1.0 / (double)total_samples), d_mean, d_packed, stream);
+  if (e == hipSuccess && rgb_linear)
+    e = hipMemcpyAsync(rgb_linear, d_mean, n * 3 * sizeof(float), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess && rgb_packed)
+    e = hipMemcpyAsync(rgb_packed, d_packed, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (d_mean) (void)hipFree(d_mean);
+  if (d_packed) (void)hipFree(d_packed);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(HT_E_HIP, "resolve failed: %s", hipGetErrorString(e));
+  }
+  return HT_OK;
+}
+
+int ht_render(ht_scene* s, const ht_camera* cam, const ht_render_params* p, float* rgb_linear,
+              uint32_t* rgb_packed, ht_stats* stats_out) {
+  if (!s || !p) return fail(HT_E_INVALID, "NULL argument");
+  if (p->width < 2 || p->height < 2)
+    return fail(HT_E_INVALID, "width and height must be >= 2 (the reference divides by W-1 and H-1)");
+  const auto t0 = std::chrono::steady_clock::now();
+  DeviceGuard g(s->device);
+  if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
+  const size_t n = (size_t)p->width * p->height;
+  float* d_accum = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_accum, n * 3 * sizeof(float)));
+  hipError_t e = hipMemsetAsync(d_accum, 0, n * 3 * sizeof(float), nullptr);
+  if (e != hipSuccess) {
+    (void)hipFree(d_accum);
+    return fail(HT_E_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+  }
+  ht_stats st;
+  int rc = ht_render_accumulate(s, cam, p, d_accum, nullptr, &st);
+  if (rc == HT_OK)
+    rc = ht_resolve(s, d_accum, p->width, p->height, p->samples, rgb_linear, rgb_packed, nullptr);
+  (void)hipFree(d_accum);
+  if (rc == HT_OK && stats_out) {
+    *stats_out = st;
+    stats_out->seconds_total =
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return rc;
+}
+
+int ht_first_hit(ht_scene* s, const ht_camera* cam, int32_t W, int32_t H, int32_t precision,
+                 float* t, int32_t* prim_id, float* normal, double* t64, double* normal64) {
+  if (!s) return fail(HT_E_INVALID, "scene is NULL");
+  int rc = check_camera(cam);
+  if (rc != HT_OK) return rc;
+  if (W < 2 || H < 2) return fail(HT_E_INVALID, "width and height must be >= 2");
+  if (precision != HT_PRECISION_FP32 && precision != HT_PRECISION_FP64)
+    return fail(HT_E_INVALID, "unknown precision %d", precision);
+  DeviceGuard g(s->device);
+  if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
+  const size_t n = (size_t)W * H;
+  const size_t rs = precision == HT_PRECISION_FP32 ? 4 : 8;
+  void *d_t = nullptr, *d_n = nullptr;
+  int32_t* d_p = nullptr;
+  hipError_t e = hipMalloc(&d_t, n * rs);
+  if (e == hipSuccess) e = hipMalloc(&d_n, n * 3 * rs);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_p, n * 4);
+  auto release = [&]() {
+    if (d_t) (void)hipFree(d_t);
+    if (d_n) (void)hipFree(d_n);
+    if (d_p) (void)hipFree(d_p);
+  };
+  if (e != hipSuccess) { release(); return fail(HT_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e)); }
+
+  CameraBasis basis;
+  camera_basis(*cam, basis);
+  CamDev<float> cam32;
+  CamDev<double> cam64;
+  fill_cam(basis, cam32);
+  fill_cam(basis, cam64);
+  FirstHitArgs a;
+  memset(&a, 0, sizeof a);
+  a.blob = precision == HT_PRECISION_FP32 ? s->d_blob32 : s->d_blob64;
+  a.L = precision == HT_PRECISION_FP32 ? s->hs.layout32 : s->hs.layout64;
+  a.W = W;
+  a.H = H;
+  a.t = d_t;
+  a.prim = d_p;
+  a.normal = d_n;
+  const uint32_t lds = lds_bytes_needed(a.L, precision);
+  e = launch_first_hit(precision, a, precision == HT_PRECISION_FP32 ? (const void*)&cam32 : (const void*)&cam64,
+                       lds, nullptr);
+  std::vector<uint8_t> ht_(n * rs), hn(n * 3 * rs);
+  if (e == hipSuccess) e = hipMemcpy(ht_.data(), d_t, n * rs, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(hn.data(), d_n, n * 3 * rs, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && prim_id) e = hipMemcpy(prim_id, d_p, n * 4, hipMemcpyDeviceToHost);
+  release();
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(HT_E_HIP, "first-hit failed: %s", hipGetErrorString(e));
+  }
+  if (precision == HT_PRECISION_FP32) {
+    const float* pt = (const float*)ht_.data();
+    const float* pn = (const float*)hn.data();
+    for (size_t i = 0; i < n; ++i) {
+      if (t) t[i] = pt[i];
+      if (t64) t64[i] = pt[i];
+    }
+    for (size_t i = 0; i < n * 3; ++i) {
+      if (normal) normal[i] = pn[i];
+      if (normal64) normal64[i] = pn[i];
+    }
+  } else {
+    const double* pt = (const double*)ht_.data();
+    const double* pn = (const double*)hn.data();
+    for (size_t i = 0; i < n; ++i) {
+      if (t) t[i] = (float)pt[i];
+      if (t64) t64[i] = pt[i];
+    }
+    for (size_t i = 0; i < n * 3; ++i) {
+      if (normal) normal[i] = (float)pn[i];
+      if (normal64) normal64[i] = pn[i];
+    }
+  }
+  return HT_OK;
+}
+
+}  // extern "C"

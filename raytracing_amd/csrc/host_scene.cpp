@@ -1,0 +1,526 @@
+// host_scene.cpp — scene validation, the library's own BVH (binned SAH, one
+// primitive per leaf, children's boxes stored in the parent) and the flattening
+// into the on-chip scene image (scene_layout.h).
+//
+// The reference builds a random-axis median-split hierarchy (BVH.scala:18-33);
+// any correct hierarchy returns the same closest hit, so this one is built for
+// traversal cost instead.  Unlike AABB.hit (AABB.scala:5-19) the boxes here are
+// conservative: flat boxes are accepted and every box is rounded outward.
+#include "host_scene.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <limits>
+
+namespace ht {
+
+namespace {
+
+struct Box {
+  double lo[3], hi[3];
+  void reset() {
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = std::numeric_limits<double>::infinity();
+      hi[a] = -std::numeric_limits<double>::infinity();
+    }
+  }
+  void grow(const Box& b) {
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = std::min(lo[a], b.lo[a]);
+      hi[a] = std::max(hi[a], b.hi[a]);
+    }
+  }
+  void grow_point(const double* p) {
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = std::min(lo[a], p[a]);
+      hi[a] = std::max(hi[a], p[a]);
+    }
+  }
+  double half_area() const {
+    double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (dx < 0 || dy < 0 || dz < 0) return 0;
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+struct Item {
+  Box box;
+  double c[3];
+  uint32_t ref;
+};
+
+// bounding boxes as the reference defines them (Hittable.scala:51, 65, 79, 93, 114)
+Box prim_box(int kind, const double* d) {
+  Box b;
+  b.reset();
+  switch (kind) {
+    case HT_PRIM_SPHERE: {
+      double r = fabs(d[3]);
+      for (int a = 0; a < 3; ++a) { b.lo[a] = d[a] - r; b.hi[a] = d[a] + r; }
+      break;
+    }
+    case HT_PRIM_XYRECT:
+      b.lo[0] = d[0]; b.hi[0] = d[1]; b.lo[1] = d[2]; b.hi[1] = d[3];
+      b.lo[2] = d[4] - 0.0001; b.hi[2] = d[4] + 0.0001;
+      break;
+    case HT_PRIM_XZRECT:
+      b.lo[0] = d[0]; b.hi[0] = d[1]; b.lo[2] = d[2]; b.hi[2] = d[3];
+      b.lo[1] = d[4] - 0.0001; b.hi[1] = d[4] + 0.0001;
+      break;
+    case HT_PRIM_YZRECT:
+      b.lo[1] = d[0]; b.hi[1] = d[1]; b.lo[2] = d[2]; b.hi[2] = d[3];
+      b.lo[0] = d[4] - 0.0001; b.hi[0] = d[4] + 0.0001;
+      break;
+    default:
+      b.grow_point(d); b.grow_point(d + 3); b.grow_point(d + 6);
+  }
+  // a rect given with swapped sides still gets a proper box
+  for (int a = 0; a < 3; ++a)
+    if (b.lo[a] > b.hi[a]) std::swap(b.lo[a], b.hi[a]);
+  return b;
+}
+
+struct Builder {
+  HostScene& hs;
+  std::vector<Item>& items;
+  int max_level = 0;
+
+  static constexpr int NBINS = 16;
+
+  // returns the reference of the subtree over items[begin, end)
+  uint32_t build(int begin, int end, int levels_left, int level, Box& out_box) {
+    const int n = end - begin;
+    if (n == 1) {
+      out_box = items[begin].box;
+      return items[begin].ref;
+    }
+    const uint32_t idx = (uint32_t)hs.nodes.size();
+    hs.nodes.emplace_back();
+    max_level = std::max(max_level, level + 1);
+
+    Box cb;
+    cb.reset();
+    for (int i = begin; i < end; ++i) cb.grow_point(items[i].c);
+
+    int best_axis = -1, best_split = -1;
+    double best_cost = std::numeric_limits<double>::infinity();
+    for (int axis = 0; axis < 3; ++axis) {
+      const double ext = cb.hi[axis] - cb.lo[axis];
+      if (!(ext > 0)) continue;
+      Box bins[NBINS];
+      int cnt[NBINS] = {0};
+      for (auto& b : bins) b.reset();
+      const double scale = NBINS / ext;
+      for (int i = begin; i < end; ++i) {
+        int k = std::min(NBINS - 1, std::max(0, (int)((items[i].c[axis] - cb.lo[axis]) * scale)));
+        bins[k].grow(items[i].box);
+        cnt[k]++;
+      }
+      double right_area[NBINS];
+      int right_cnt[NBINS];
+      Box acc;
+      acc.reset();
+      int c = 0;
+      for (int k = NBINS - 1; k > 0; --k) {
+        acc.grow(bins[k]);
+        c += cnt[k];
+        right_area[k] = acc.half_area();
+        right_cnt[k] = c;
+      }
+      acc.reset();
+      c = 0;
+      for (int k = 0; k < NBINS - 1; ++k) {
+        acc.grow(bins[k]);
+        c += cnt[k];
+        if (c == 0 || right_cnt[k + 1] == 0) continue;
+        double cost = acc.half_area() * c + right_area[k + 1] * right_cnt[k + 1];
+        if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = k; }
+      }
+    }
+
+    int mid = -1;
+    if (best_axis >= 0) {
+      const double ext = cb.hi[best_axis] - cb.lo[best_axis];
+      const double scale = NBINS / ext;
+      const double lo = cb.lo[best_axis];
+      const int ax = best_axis, sp = best_split;
+      auto it = std::stable_partition(items.begin() + begin, items.begin() + end, [&](const Item& it2) {
+        int k = std::min(NBINS - 1, std::max(0, (int)((it2.c[ax] - lo) * scale)));
+        return k <= sp;
+      });
+      mid = (int)(it - items.begin());
+    }
+    // the traversal stack is bounded: a side must still fit in the levels left
+    const int cap = (levels_left - 1 >= 30) ? (1 << 30) : (1 << std::max(0, levels_left - 1));
+    if (mid <= begin || mid >= end || (mid - begin) > cap || (end - mid) > cap) {
+      int axis = 0;
+      for (int a = 1; a < 3; ++a)
+        if (cb.hi[a] - cb.lo[a] > cb.hi[axis] - cb.lo[axis]) axis = a;
+      std::stable_sort(items.begin() + begin, items.begin() + end,
+                       [axis](const Item& x, const Item& y) { return x.c[axis] < y.c[axis]; });
+      mid = begin + n / 2;
+    }
+    Box lb, rb;
+    uint32_t l = build(begin, mid, levels_left - 1, level + 1, lb);
+    uint32_t r = build(mid, end, levels_left - 1, level + 1, rb);
+    BvhNode& nd = hs.nodes[idx];
+    for (int a = 0; a < 3; ++a) {
+      nd.lo[0][a] = lb.lo[a]; nd.hi[0][a] = lb.hi[a];
+      nd.lo[1][a] = rb.lo[a]; nd.hi[1][a] = rb.hi[a];
+    }
+    nd.child[0] = l;
+    nd.child[1] = r;
+    out_box = lb;
+    out_box.grow(rb);
+    return idx;
+  }
+};
+
+// ---- blob writer -------------------------------------------------------------
+template <typename R> R round_down(double d);
+template <typename R> R round_up(double d);
+template <> double round_down<double>(double d) { return nextafter(d, -INFINITY); }
+template <> double round_up<double>(double d) { return nextafter(d, INFINITY); }
+template <> float round_down<float>(double d) {
+  float f = (float)d;
+  if ((double)f > d) f = nextafterf(f, -INFINITY);
+  return nextafterf(f, -INFINITY);
+}
+template <> float round_up<float>(double d) {
+  float f = (float)d;
+  if ((double)f < d) f = nextafterf(f, INFINITY);
+  return nextafterf(f, INFINITY);
+}
+
+struct Blob {
+  std::vector<uint8_t>& b;
+  uint32_t reserve(size_t bytes) {
+    size_t off = (b.size() + 15) & ~(size_t)15;
+    b.resize(off + bytes, 0);
+    return (uint32_t)off;
+  }
+  template <typename T> void put(uint32_t off, T v) { memcpy(b.data() + off, &v, sizeof(T)); }
+};
+
+// a u32 stored in the low 32 bits of an R-sized slot
+template <typename R> void put_bits(Blob& bl, uint32_t off, uint32_t v) {
+  if (sizeof(R) == 8) bl.put<uint64_t>(off, (uint64_t)v);
+  else bl.put<uint32_t>(off, v);
+}
+
+template <typename R>
+void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out) {
+  out.clear();
+  Blob bl{out};
+  const uint32_t RS = sizeof(R);
+  memset(&L, 0, sizeof L);
+  L.n_nodes = (uint32_t)hs.nodes.size();
+  L.n_sph = (uint32_t)hs.sph.size();
+  L.n_rect = (uint32_t)hs.rect.size();
+  L.n_tri = (uint32_t)hs.tri.size();
+  L.n_mat = (uint32_t)hs.mat_type.size();
+  L.n_tex = (uint32_t)hs.tex_type.size();
+  L.n_perlin = (uint32_t)hs.n_perlin;
+  L.n_images = (uint32_t)hs.image_width.size();
+  L.depth = (uint32_t)hs.depth;
+
+  const uint32_t ns = node_stride<R>();
+  L.nodes = bl.reserve((size_t)L.n_nodes * ns);
+  for (uint32_t i = 0; i < L.n_nodes; ++i) {
+    const BvhNode& n = hs.nodes[i];
+    uint32_t o = L.nodes + i * ns;
+    for (int c = 0; c < 2; ++c) {
+      for (int a = 0; a < 3; ++a) bl.put<R>(o + (c * 6 + a) * RS, round_down<R>(n.lo[c][a]));
+      for (int a = 0; a < 3; ++a) bl.put<R>(o + (c * 6 + 3 + a) * RS, round_up<R>(n.hi[c][a]));
+    }
+    bl.put<uint32_t>(o + 12 * RS, n.child[0] | (n.child[1] << 16));
+  }
+
+  L.sph = bl.reserve((size_t)L.n_sph * 4 * RS);
+  L.sph_k = bl.reserve((size_t)L.n_sph * RS);
+  L.meta_sph = bl.reserve((size_t)L.n_sph * 4);
+  for (uint32_t i = 0; i < L.n_sph; ++i) {
+    int p = hs.sph[i];
+    const double* d = &hs.prim_data[(size_t)p * HT_PRIM_STRIDE];
+    for (int a = 0; a < 4; ++a) bl.put<R>(L.sph + (i * 4 + a) * RS, (R)d[a]);
+    double K = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] - d[3] * d[3];
+    bl.put<R>(L.sph_k + i * RS, (R)K);
+    bl.put<uint32_t>(L.meta_sph + i * 4, ((uint32_t)hs.prim_material[p] << META_MAT_SHIFT) | (uint32_t)p);
+  }
+
+  L.rect = bl.reserve((size_t)L.n_rect * 8 * RS);
+  L.meta_rect = bl.reserve((size_t)L.n_rect * 4);
+  for (uint32_t i = 0; i < L.n_rect; ++i) {
+    int p = hs.rect[i];
+    const double* d = &hs.prim_data[(size_t)p * HT_PRIM_STRIDE];
+    for (int a = 0; a < 5; ++a) bl.put<R>(L.rect + (i * 8 + a) * RS, (R)d[a]);
+    bl.put<uint32_t>(L.meta_rect + i * 4, ((uint32_t)hs.prim_material[p] << META_MAT_SHIFT) | (uint32_t)p);
+  }
+
+  L.tri = bl.reserve((size_t)L.n_tri * 12 * RS);
+  L.meta_tri = bl.reserve((size_t)L.n_tri * 4);
+  for (uint32_t i = 0; i < L.n_tri; ++i) {
+    int p = hs.tri[i];
+    const double* d = &hs.prim_data[(size_t)p * HT_PRIM_STRIDE];
+    // edges and normal in fp64 (Hittable.scala:98-100), rounded once
+    double e1[3], e2[3], n[3];
+    for (int a = 0; a < 3; ++a) { e1[a] = d[3 + a] - d[a]; e2[a] = d[6 + a] - d[a]; }
+    n[0] = e1[1] * e2[2] - e1[2] * e2[1];
+    n[1] = e1[2] * e2[0] - e1[0] * e2[2];
+    n[2] = e1[0] * e2[1] - e1[1] * e2[0];
+    uint32_t o = L.tri + i * 12 * RS;
+    for (int a = 0; a < 3; ++a) {
+      bl.put<R>(o + a * RS, (R)d[a]);
+      bl.put<R>(o + (3 + a) * RS, (R)e1[a]);
+      bl.put<R>(o + (6 + a) * RS, (R)e2[a]);
+      bl.put<R>(o + (9 + a) * RS, (R)n[a]);
+    }
+    bl.put<uint32_t>(L.meta_tri + i * 4, ((uint32_t)hs.prim_material[p] << META_MAT_SHIFT) | (uint32_t)p);
+  }
+
+  L.mat = bl.reserve((size_t)L.n_mat * 4 * RS);
+  for (uint32_t i = 0; i < L.n_mat; ++i) {
+    put_bits<R>(bl, L.mat + i * 4 * RS, (uint32_t)hs.mat_type[i] | ((uint32_t)hs.mat_texture[i] << 4));
+    bl.put<R>(L.mat + (i * 4 + 1) * RS, (R)hs.mat_param[i]);
+  }
+
+  L.tex = bl.reserve((size_t)L.n_tex * 4 * RS);
+  for (uint32_t i = 0; i < L.n_tex; ++i) {
+    const double* d = &hs.tex_data[(size_t)i * HT_TEX_STRIDE];
+    for (int a = 0; a < 3; ++a) bl.put<R>(L.tex + (i * 4 + a) * RS, (R)d[a]);
+    uint32_t kind = (uint32_t)hs.tex_type[i];
+    uint32_t c0 = 0, c1 = 0;
+    if (kind == HT_TEX_CHECKER) { c0 = (uint32_t)hs.tex_child[i * 2]; c1 = (uint32_t)hs.tex_child[i * 2 + 1]; }
+    else if (kind != HT_TEX_SOLID) { c0 = (uint32_t)hs.tex_child[i * 2]; }
+    put_bits<R>(bl, L.tex + (i * 4 + 3) * RS, kind | (c0 << 2) | (c1 << 17));
+    if (kind == HT_TEX_IMAGE) L.has_uv_textures = 1;
+  }
+
+  L.perlin_stride = 256u * 4u * RS + 768u;
+  L.perlin = bl.reserve((size_t)L.n_perlin * L.perlin_stride);
+  for (uint32_t t = 0; t < L.n_perlin; ++t) {
+    uint32_t o = L.perlin + t * L.perlin_stride;
+    for (int i = 0; i < 256; ++i)
+      for (int a = 0; a < 3; ++a)
+        bl.put<R>(o + (i * 4 + a) * RS, (R)hs.perlin_ranvec[((size_t)t * 256 + i) * 3 + a]);
+    for (int i = 0; i < 768; ++i)
+      bl.put<uint8_t>(o + 256u * 4u * RS + i, (uint8_t)hs.perlin_perm[(size_t)t * 768 + i]);
+  }
+
+  L.images = bl.reserve((size_t)L.n_images * 16);
+  for (uint32_t i = 0; i < L.n_images; ++i) {
+    bl.put<uint32_t>(L.images + i * 16, (uint32_t)hs.image_width[i]);
+    bl.put<uint32_t>(L.images + i * 16 + 4, (uint32_t)hs.image_height[i]);
+    bl.put<uint32_t>(L.images + i * 16 + 8, (uint32_t)((uint64_t)hs.image_offset[i] & 0xFFFFFFFFu));
+    bl.put<uint32_t>(L.images + i * 16 + 12, (uint32_t)((uint64_t)hs.image_offset[i] >> 32));
+  }
+  L.total_bytes = bl.reserve(0);
+  out.resize(L.total_bytes);
+}
+
+bool texture_acyclic(const HostScene& hs, int t, int depth) {
+  if (depth > (int)hs.tex_type.size()) return false;
+  if (hs.tex_type[t] != HT_TEX_CHECKER) return true;
+  return texture_acyclic(hs, hs.tex_child[t * 2], depth + 1) &&
+         texture_acyclic(hs, hs.tex_child[t * 2 + 1], depth + 1);
+}
+
+}  // namespace
+
+int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err) {
+  if (!d) { err = "scene description is NULL"; return HT_E_INVALID; }
+  if (d->n_prims <= 0 || !d->prim_type || !d->prim_material || !d->prim_data) {
+    err = "scene has no primitives (the reference cannot build a BVH over an empty world either)";
+    return HT_E_INVALID;
+  }
+  if (d->n_materials <= 0 || !d->mat_type || !d->mat_texture || !d->mat_param) {
+    err = "scene has no materials"; return HT_E_INVALID;
+  }
+  if (d->n_textures <= 0 || !d->tex_type || !d->tex_data || !d->tex_child) {
+    err = "scene has no textures"; return HT_E_INVALID;
+  }
+  if ((uint32_t)d->n_prims > MAX_PRIMS) { err = "too many primitives"; return HT_E_TOO_LARGE; }
+  if ((uint32_t)d->n_materials > MAX_MATERIALS) { err = "too many materials"; return HT_E_TOO_LARGE; }
+  if ((uint32_t)d->n_textures > MAX_TEXTURES) { err = "too many textures"; return HT_E_TOO_LARGE; }
+  if (d->n_images < 0 || d->n_perlin < 0) { err = "negative table count"; return HT_E_INVALID; }
+
+  hs.prim_type.assign(d->prim_type, d->prim_type + d->n_prims);
+  hs.prim_material.assign(d->prim_material, d->prim_material + d->n_prims);
+  hs.prim_data.assign(d->prim_data, d->prim_data + (size_t)d->n_prims * HT_PRIM_STRIDE);
+  hs.mat_type.assign(d->mat_type, d->mat_type + d->n_materials);
+  hs.mat_texture.assign(d->mat_texture, d->mat_texture + d->n_materials);
+  hs.mat_param.assign(d->mat_param, d->mat_param + d->n_materials);
+  hs.tex_type.assign(d->tex_type, d->tex_type + d->n_textures);
+  hs.tex_data.assign(d->tex_data, d->tex_data + (size_t)d->n_textures * HT_TEX_STRIDE);
+  hs.tex_child.assign(d->tex_child, d->tex_child + (size_t)d->n_textures * 2);
+  if (d->n_images > 0) {
+    if (!d->image_width || !d->image_height || !d->image_offset || !d->image_texels) {
+      err = "image tables missing"; return HT_E_INVALID;
+    }
+    hs.image_width.assign(d->image_width, d->image_width + d->n_images);
+    hs.image_height.assign(d->image_height, d->image_height + d->n_images);
+    hs.image_offset.assign(d->image_offset, d->image_offset + d->n_images);
+    int64_t total = 0;
+    for (int k = 0; k < d->n_images; ++k) {
+      if (hs.image_width[k] <= 0 || hs.image_height[k] <= 0 || hs.image_offset[k] < 0) {
+        err = "bad image dimensions"; return HT_E_INVALID;
+      }
+      total = std::max(total, hs.image_offset[k] + (int64_t)hs.image_width[k] * hs.image_height[k]);
+    }
+    hs.image_texels.assign(d->image_texels, d->image_texels + total);
+  }
+  hs.n_perlin = d->n_perlin;
+  if (d->n_perlin > 0) {
+    if (!d->perlin_ranvec || !d->perlin_perm) { err = "perlin tables missing"; return HT_E_INVALID; }
+    hs.perlin_ranvec.assign(d->perlin_ranvec, d->perlin_ranvec + (size_t)d->n_perlin * 768);
+    hs.perlin_perm.assign(d->perlin_perm, d->perlin_perm + (size_t)d->n_perlin * 768);
+    for (int32_t v : hs.perlin_perm)
+      if (v < 0 || v > 255) { err = "perlin permutation entry out of range"; return HT_E_INVALID; }
+  }
+
+  for (int i = 0; i < d->n_textures; ++i) {
+    int k = hs.tex_type[i];
+    if (k < HT_TEX_SOLID || k > HT_TEX_IMAGE) { err = "unknown texture type"; return HT_E_INVALID; }
+    if (k == HT_TEX_CHECKER) {
+      for (int c = 0; c < 2; ++c) {
+        int ch = hs.tex_child[i * 2 + c];
+        if (ch < 0 || ch >= d->n_textures) { err = "checker child out of range"; return HT_E_INVALID; }
+      }
+    } else if (k == HT_TEX_PERLIN) {
+      int t = hs.tex_child[i * 2];
+      if (t < 0 || t >= d->n_perlin) { err = "perlin table index out of range"; return HT_E_INVALID; }
+    } else if (k == HT_TEX_IMAGE) {
+      int t = hs.tex_child[i * 2];
+      if (t < 0 || t >= d->n_images) { err = "image index out of range"; return HT_E_INVALID; }
+    }
+  }
+  for (int i = 0; i < d->n_textures; ++i)
+    if (!texture_acyclic(hs, i, 0)) { err = "checker textures form a cycle"; return HT_E_INVALID; }
+  for (int i = 0; i < d->n_materials; ++i) {
+    if (hs.mat_type[i] < HT_MAT_DIFFUSE || hs.mat_type[i] > HT_MAT_EMISSION) {
+      err = "unknown material type"; return HT_E_INVALID;
+    }
+    if (hs.mat_texture[i] < 0 || hs.mat_texture[i] >= d->n_textures) {
+      err = "material texture out of range"; return HT_E_INVALID;
+    }
+  }
+
+  // ---- per-kind arrays and leaf references ---------------------------------
+  const int n = d->n_prims;
+  std::vector<Box> boxes(n);
+  for (int p = 0; p < n; ++p) {
+    int k = hs.prim_type[p];
+    if (k < HT_PRIM_SPHERE || k > HT_PRIM_TRIANGLE) { err = "unknown primitive type"; return HT_E_INVALID; }
+    if (hs.prim_material[p] < 0 || hs.prim_material[p] >= d->n_materials) {
+      err = "primitive material out of range"; return HT_E_INVALID;
+    }
+    const double* pd = &hs.prim_data[(size_t)p * HT_PRIM_STRIDE];
+    int used = (k == HT_PRIM_SPHERE) ? 4 : (k == HT_PRIM_TRIANGLE ? 9 : 5);
+    for (int a = 0; a < used; ++a)
+      if (!std::isfinite(pd[a])) { err = "non-finite primitive coordinate"; return HT_E_INVALID; }
+    if (k == HT_PRIM_SPHERE && pd[3] == 0.0) { err = "sphere of radius 0"; return HT_E_INVALID; }
+    boxes[p] = prim_box(k, pd);
+  }
+  hs.prim_ref.assign(n, 0);
+  for (int p = 0; p < n; ++p) {
+    int k = hs.prim_type[p];
+    if (k == HT_PRIM_SPHERE) {
+      hs.sph.push_back(p);
+    } else if (k == HT_PRIM_TRIANGLE) {
+      hs.prim_ref[p] = REF_LEAF | (KIND_TRIANGLE << REF_KIND_SHIFT) | (uint32_t)hs.tri.size();
+      hs.tri.push_back(p);
+    } else {
+      uint32_t kind = k == HT_PRIM_XYRECT ? KIND_XYRECT : (k == HT_PRIM_XZRECT ? KIND_XZRECT : KIND_YZRECT);
+      hs.prim_ref[p] = REF_LEAF | (kind << REF_KIND_SHIFT) | (uint32_t)hs.rect.size();
+      hs.rect.push_back(p);
+    }
+  }
+  if (hs.sph.size() > MAX_PER_KIND || hs.rect.size() > MAX_PER_KIND || hs.tri.size() > MAX_PER_KIND) {
+    err = "more than 4096 primitives of one kind: beyond the on-chip scene store";
+    return HT_E_TOO_LARGE;
+  }
+  // A sphere that dwarfs everything else (a "ground" sphere) is intersected in
+  // the expanded form |o|^2 - 2 o.c + (|c|^2 - r^2): its error scales with the
+  // distance of the ray origin from the WORLD origin, not with r^2.
+  hs.sph_big.assign(hs.sph.size(), 0);
+  for (size_t i = 0; i < hs.sph.size(); ++i) {
+    int p = hs.sph[i];
+    const double* pd = &hs.prim_data[(size_t)p * HT_PRIM_STRIDE];
+    double r = fabs(pd[3]);
+    double E = 0;  // radius about the world origin of everything else in the scene
+    for (int q = 0; q < n; ++q) {
+      if (q == p) continue;
+      const Box& b = boxes[q];
+      double m = 0;
+      for (int a = 0; a < 3; ++a) { double v = std::max(fabs(b.lo[a]), fabs(b.hi[a])); m += v * v; }
+      E = std::max(E, sqrt(m));
+    }
+    double cl = sqrt(pd[0] * pd[0] + pd[1] * pd[1] + pd[2] * pd[2]);
+    double K = fabs(cl * cl - r * r);
+    bool big = 4.0 * (E * E + 2.0 * E * cl + K) < r * r;
+    hs.sph_big[i] = big ? 1 : 0;
+    hs.prim_ref[p] = REF_LEAF | ((big ? KIND_BIG_SPHERE : KIND_SPHERE) << REF_KIND_SHIFT) | (uint32_t)i;
+  }
+
+  // ---- hierarchy ---------------------------------------------------------------
+  std::vector<Item> items(n);
+  for (int p = 0; p < n; ++p) {
+    items[p].box = boxes[p];
+    for (int a = 0; a < 3; ++a) items[p].c[a] = 0.5 * (boxes[p].lo[a] + boxes[p].hi[a]);
+    items[p].ref = hs.prim_ref[p];
+  }
+  hs.nodes.clear();
+  if (n == 1) {
+    // like the reference's BVH(only, only) (BVH.scala:30): the same leaf twice
+    BvhNode nd;
+    for (int c = 0; c < 2; ++c)
+      for (int a = 0; a < 3; ++a) { nd.lo[c][a] = boxes[0].lo[a]; nd.hi[c][a] = boxes[0].hi[a]; }
+    nd.child[0] = nd.child[1] = items[0].ref;
+    hs.nodes.push_back(nd);
+    hs.depth = 1;
+  } else {
+    Builder b{hs, items};
+    Box root;
+    b.build(0, n, STACK_MAX_DEPTH, 0, root);
+    hs.depth = b.max_level;
+  }
+  if (hs.nodes.size() > MAX_NODES) { err = "too many BVH nodes"; return HT_E_TOO_LARGE; }
+
+  write_blob<float>(hs, hs.layout32, hs.blob32);
+  write_blob<double>(hs, hs.layout64, hs.blob64);
+  return HT_OK;
+}
+
+// Camera.scala:5-17
+void camera_basis(const ht_camera& in, CameraBasis& c) {
+  auto sub = [](const double* a, const double* b, double* o) { for (int i = 0; i < 3; ++i) o[i] = a[i] - b[i]; };
+  auto len = [](const double* a) { return sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); };
+  auto unit = [&](double* a) { double l = len(a); for (int i = 0; i < 3; ++i) a[i] /= l; };
+  auto cross = [](const double* a, const double* b, double* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+  };
+  const double viewport_height = 2.0 * tan(in.vfov * 0.017453292519943295 / 2);
+  const double viewport_width = in.aspect_ratio * viewport_height;
+  sub(in.origin, in.target, c.w);
+  unit(c.w);
+  cross(in.vup, c.w, c.u);
+  unit(c.u);
+  cross(c.w, c.u, c.v);
+  double to[3];
+  sub(in.target, in.origin, to);
+  const double focus = in.focus_distance < 0 ? len(to) : in.focus_distance;
+  for (int i = 0; i < 3; ++i) {
+    c.horizontal[i] = (focus * viewport_width) * c.u[i];
+    c.vertical[i] = (focus * viewport_height) * c.v[i];
+    c.llc[i] = in.origin[i] - c.horizontal[i] / 2 - c.vertical[i] / 2 - focus * c.w[i];
+    c.origin[i] = in.origin[i];
+    c.background[i] = in.background[i];
+  }
+  c.lens_radius = in.aperture / 2;
+}
+
+}  // namespace ht

@@ -1,0 +1,56 @@
+// host_scene.h — host side of a scene handle: validated copy of the caller's
+// description, the library's own BVH, and the two on-chip scene images.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/hiptrace.h"
+#include "scene_layout.h"
+
+namespace ht {
+
+struct BvhNode {
+  double lo[2][3], hi[2][3];  // boxes of the two children
+  uint32_t child[2];          // 16-bit references (scene_layout.h)
+};
+
+struct HostScene {
+  // validated copies (fp64, as handed over)
+  std::vector<int32_t> prim_type, prim_material;
+  std::vector<double> prim_data;
+  std::vector<int32_t> mat_type, mat_texture;
+  std::vector<double> mat_param;
+  std::vector<int32_t> tex_type, tex_child;
+  std::vector<double> tex_data;
+  std::vector<int32_t> image_width, image_height;
+  std::vector<int64_t> image_offset;
+  std::vector<uint32_t> image_texels;
+  std::vector<double> perlin_ranvec;
+  std::vector<int32_t> perlin_perm;
+  int32_t n_perlin = 0;
+
+  // per-kind arrays: primitive ids in kind-local order
+  std::vector<int32_t> sph, rect, tri;
+  std::vector<uint8_t> sph_big;     // KIND_BIG_SPHERE flag per entry of sph
+  std::vector<uint32_t> prim_ref;   // leaf reference of every primitive
+
+  std::vector<BvhNode> nodes;
+  int depth = 0;
+
+  SceneLayout layout32{}, layout64{};
+  std::vector<uint8_t> blob32, blob64;
+};
+
+// Validates `desc` and fills `out`; returns HT_OK or an error code with `err` set.
+int build_host_scene(const ht_scene_desc* desc, HostScene& out, std::string& err);
+
+// Camera.scala:5-17 in fp64: origin, lower_left_corner, horizontal, vertical, u, v, w, lens_radius
+struct CameraBasis {
+  double origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3], w[3], background[3];
+  double lens_radius;
+};
+void camera_basis(const ht_camera& cam, CameraBasis& out);
+
+}  // namespace ht

@@ -1,0 +1,69 @@
+// kernels.h — host-callable launchers of the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "scene_layout.h"
+
+namespace ht {
+
+// Camera basis of Camera.scala:5-17 (reference), computed on the host in fp64
+// and rounded to the kernel's arithmetic type.
+template <typename R>
+struct CamDev {
+  R origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3], background[3];
+  R lens_radius;
+};
+
+struct RenderArgs {
+  const uint8_t* blob;     // scene image in global memory (copied to LDS per workgroup)
+  SceneLayout L;
+  const uint32_t* texels;  // image texels, 0x00RRGGBB
+  float* accum;            // [H*W*3] radiance sums, row 0 = bottom
+  uint32_t* tile_counter;  // zeroed before every launch
+  unsigned long long* counters;  // NUM_COUNTERS words, or nullptr
+  int32_t W, H;
+  int32_t sample_first;    // global index of the first sample of this launch
+  int32_t sample_count;    // samples per pixel in this launch
+  int32_t max_depth;
+  int32_t jitter;
+  uint32_t seed_lo, seed_hi;
+  int32_t wait_threshold;  // lanes that may wait for shading before traversal yields
+};
+
+struct FirstHitArgs {
+  const uint8_t* blob;
+  SceneLayout L;
+  int32_t W, H;
+  void* t;        // R [H*W]
+  int32_t* prim;  // [H*W]
+  void* normal;   // R [H*W*3]
+};
+
+enum {
+  CTR_RAYS = 0, CTR_BOX, CTR_SPHERE, CTR_RECT, CTR_TRI,
+  CTR_SHADE0, CTR_SHADE1, CTR_SHADE2, CTR_SHADE3,
+  CTR_TEX0, CTR_TEX1, CTR_TEX2, CTR_TEX3,
+  CTR_STEPS, CTR_ACTIVE,
+  NUM_COUNTERS
+};
+
+constexpr int BLOCK_THREADS = 1024;
+constexpr int TILE_W = 8, TILE_H = 8;
+
+// dynamic LDS bytes a render / first-hit launch needs for layout L
+uint32_t lds_bytes_needed(const SceneLayout& L, int precision);
+
+// Returns the number of workgroups per CU the device can hold for this kernel
+// and LDS size (0: does not fit).
+int render_blocks_per_cu(int precision, bool counters, uint32_t lds_bytes);
+
+hipError_t launch_render(int precision, bool counters, const RenderArgs& a, const void* cam,
+                         int grid_blocks, uint32_t lds_bytes, hipStream_t stream);
+hipError_t launch_first_hit(int precision, const FirstHitArgs& a, const void* cam,
+                            uint32_t lds_bytes, hipStream_t stream);
+// mean + Vec3.toRGB + row flip (Vec3.scala:82-84, main.scala:93)
+hipError_t launch_resolve(const float* accum, int32_t W, int32_t H, float inv_samples,
+                          float* rgb_mean, uint32_t* rgb_packed, hipStream_t stream);
+
+}  // namespace ht

@@ -1,0 +1,936 @@
+// kernels.hip — gfx950 (MI355X, wave64) kernels of libhiptrace.
+//
+// One persistent "megakernel" does everything between a pixel index and its
+// radiance sum: camera ray generation, BVH traversal, primitive intersection,
+// material scatter and texture evaluation, for `sample_count` paths per pixel.
+//
+// Execution model
+//  * a workgroup copies the scene image (scene_layout.h) into LDS once; every
+//    scene of the reference fits (<= ~60 KB), so traversal never touches HBM.
+//    Image texels are the only global reads.
+//  * each wave pulls 8x8-pixel tiles from a global counter; lane = pixel.
+//  * lanes are small state machines (TRAV / WAIT / DEAD / DONE).  The wave runs
+//    traversal steps while enough lanes are traversing; when `wait_threshold`
+//    lanes have finished their ray, the wave shades them, regenerates camera
+//    paths for the dead ones (next sample of the same pixel) and goes back to
+//    traversal with the stragglers still in mid-flight, so no lane idles for
+//    the length of the longest path in the wave.
+//  * the per-lane traversal stack lives in LDS, [level][thread] u32 entries:
+//    bf16(entry distance) << 16 | 16-bit node reference.
+//  * random numbers: Philox4x32-10, counter = (pixel, sample, bounce, 0),
+//    key = seed; one block per event.
+//
+// Reference semantics reproduced here (Ivoah/RayTracing, S = shared/src/main/scala):
+//  S/Camera.scala:19-36, S/Hittable.scala:4-115, S/Material.scala:4-55,
+//  S/Texture.scala:12-107, S/Vec3.scala:17-34,82-84 and the loop at
+//  jvm/src/main/scala/main.scala:79-94.  Directions are never normalised, rect
+//  normals are always +z and triangle normals are the raw cross product, as in
+//  the reference.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace ht {
+
+// ---------------------------------------------------------------------------
+// arithmetic traits
+// ---------------------------------------------------------------------------
+template <typename R> struct M;
+
+template <> struct M<float> {
+  typedef float4 R4;
+  static constexpr int BT = 1024;  // threads per workgroup
+  static __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+  static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+  static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+  static __device__ __forceinline__ float fmin(float a, float b) { return __builtin_fminf(a, b); }
+  static __device__ __forceinline__ float fmax(float a, float b) { return __builtin_fmaxf(a, b); }
+  static __device__ __forceinline__ float fabs(float a) { return __builtin_fabsf(a); }
+  static __device__ __forceinline__ float floor(float a) { return __builtin_floorf(a); }
+  static __device__ __forceinline__ float copysign(float a, float b) { return __builtin_copysignf(a, b); }
+  // sin / cos of 2*pi*u, u in [0,1): v_sin_f32 / v_cos_f32 take revolutions
+  static __device__ __forceinline__ void sincos2pi(float u, float& s, float& c) {
+    s = __builtin_amdgcn_sinf(u);
+    c = __builtin_amdgcn_cosf(u);
+  }
+  static __device__ __forceinline__ float sin(float x) {
+    float r = x * 0.15915494309189535f;
+    return __builtin_amdgcn_sinf(r - __builtin_floorf(r));
+  }
+  static __device__ __forceinline__ float cbrt(float x) { return ::cbrtf(x); }
+  static __device__ __forceinline__ float atan2(float y, float x) { return ::atan2f(y, x); }
+  static __device__ __forceinline__ float asin(float x) { return ::asinf(x); }
+  static __device__ __forceinline__ float inf() { return __builtin_huge_valf(); }
+  static __device__ __forceinline__ uint32_t bits_lo(float x) { return __float_as_uint(x); }
+  static __device__ __forceinline__ float to_float_down(float x) { return x; }
+  static __device__ __forceinline__ float slab_widen() { return 1.0000005f; }
+};
+
+template <> struct M<double> {
+  typedef double4 R4;
+  static constexpr int BT = 512;
+  static __device__ __forceinline__ double rcp(double x) { return 1.0 / x; }
+  static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+  static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
+  static __device__ __forceinline__ double fmin(double a, double b) { return ::fmin(a, b); }
+  static __device__ __forceinline__ double fmax(double a, double b) { return ::fmax(a, b); }
+  static __device__ __forceinline__ double fabs(double a) { return ::fabs(a); }
+  static __device__ __forceinline__ double floor(double a) { return ::floor(a); }
+  static __device__ __forceinline__ double copysign(double a, double b) { return ::copysign(a, b); }
+  static __device__ __forceinline__ void sincos2pi(double u, double& s, double& c) {
+    ::sincos(6.283185307179586476925 * u, &s, &c);
+  }
+  static __device__ __forceinline__ double sin(double x) { return ::sin(x); }
+  static __device__ __forceinline__ double cbrt(double x) { return ::cbrt(x); }
+  static __device__ __forceinline__ double atan2(double y, double x) { return ::atan2(y, x); }
+  static __device__ __forceinline__ double asin(double x) { return ::asin(x); }
+  static __device__ __forceinline__ double inf() { return __builtin_huge_val(); }
+  static __device__ __forceinline__ uint32_t bits_lo(double x) {
+    return (uint32_t)__double_as_longlong(x);
+  }
+  static __device__ __forceinline__ float to_float_down(double x) { return __double2float_rd(x); }
+  static __device__ __forceinline__ double slab_widen() { return 1.0000000000001; }
+};
+
+template <typename R> struct V3 { R x, y, z; };
+template <typename R> __device__ __forceinline__ V3<R> mk(R x, R y, R z) { V3<R> r; r.x = x; r.y = y; r.z = z; return r; }
+template <typename R> __device__ __forceinline__ V3<R> operator+(V3<R> a, V3<R> b) { return mk<R>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename R> __device__ __forceinline__ V3<R> operator-(V3<R> a, V3<R> b) { return mk<R>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <typename R> __device__ __forceinline__ V3<R> operator*(V3<R> a, V3<R> b) { return mk<R>(a.x * b.x, a.y * b.y, a.z * b.z); }
+template <typename R> __device__ __forceinline__ V3<R> operator*(R s, V3<R> a) { return mk<R>(s * a.x, s * a.y, s * a.z); }
+template <typename R> __device__ __forceinline__ V3<R> operator-(V3<R> a) { return mk<R>(-a.x, -a.y, -a.z); }
+template <typename R> __device__ __forceinline__ R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename R> __device__ __forceinline__ V3<R> cross(V3<R> a, V3<R> b) {
+  return mk<R>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+template <typename R> __device__ __forceinline__ V3<R> ld3(const R* p) { return mk<R>(p[0], p[1], p[2]); }
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// 24-bit uniform in [0,1): exactly representable in fp32 and fp64
+template <typename R> __device__ __forceinline__ R u01(uint32_t x) {
+  return (R)(x >> 8) * (R)(1.0 / 16777216.0);
+}
+
+// ---------------------------------------------------------------------------
+// scene image accessors (LDS)
+// ---------------------------------------------------------------------------
+struct Scene {
+  const uint8_t* base;  // LDS
+  SceneLayout L;
+};
+
+template <typename R>
+__device__ __forceinline__ void load_node(const Scene& sc, uint32_t idx, R b[12], uint32_t& cc);
+
+template <>
+__device__ __forceinline__ void load_node<float>(const Scene& sc, uint32_t idx, float b[12], uint32_t& cc) {
+  const uint8_t* p = sc.base + sc.L.nodes + idx * 64u;
+  float4 a0 = *(const float4*)(p);
+  float4 a1 = *(const float4*)(p + 16);
+  float4 a2 = *(const float4*)(p + 32);
+  cc = *(const uint32_t*)(p + 48);
+  b[0] = a0.x; b[1] = a0.y; b[2] = a0.z; b[3] = a0.w;
+  b[4] = a1.x; b[5] = a1.y; b[6] = a1.z; b[7] = a1.w;
+  b[8] = a2.x; b[9] = a2.y; b[10] = a2.z; b[11] = a2.w;
+}
+template <>
+__device__ __forceinline__ void load_node<double>(const Scene& sc, uint32_t idx, double b[12], uint32_t& cc) {
+  const uint8_t* p = sc.base + sc.L.nodes + idx * 112u;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double2 v = *(const double2*)(p + 16 * i);
+    b[2 * i] = v.x;
+    b[2 * i + 1] = v.y;
+  }
+  cc = *(const uint32_t*)(p + 96);
+}
+
+template <typename R>
+__device__ __forceinline__ typename M<R>::R4 load_r4(const Scene& sc, uint32_t off, uint32_t idx) {
+  return *(const typename M<R>::R4*)(sc.base + off + idx * (uint32_t)(4 * sizeof(R)));
+}
+__device__ __forceinline__ uint32_t load_u32(const Scene& sc, uint32_t off, uint32_t idx) {
+  return *(const uint32_t*)(sc.base + off + idx * 4u);
+}
+
+// ---------------------------------------------------------------------------
+// ray + traversal state
+// ---------------------------------------------------------------------------
+template <typename R>
+struct Ray {
+  V3<R> o, d, inv;  // inv = 1/d per component
+  R a, inv_a, oo;   // |d|^2, 1/|d|^2, |o|^2
+};
+
+template <typename R>
+__device__ __forceinline__ void ray_setup(Ray<R>& r) {
+  r.inv = mk<R>(M<R>::rcp(r.d.x), M<R>::rcp(r.d.y), M<R>::rcp(r.d.z));
+  r.a = dot(r.d, r.d);
+  r.inv_a = M<R>::rcp(r.a);
+  r.oo = dot(r.o, r.o);
+}
+
+template <typename R>
+struct Trav {
+  uint32_t cur;       // reference being processed; REF_EMPTY when the ray is finished
+  uint32_t sp;        // stack entries in use
+  uint32_t best_ref;  // REF_EMPTY = no hit yet
+  R best_t;
+};
+
+template <typename R>
+__device__ __forceinline__ void trav_begin(Trav<R>& tv) {
+  tv.cur = 0;  // root is inner node 0
+  tv.sp = 0;
+  tv.best_ref = REF_EMPTY;
+  tv.best_t = M<R>::inf();
+}
+
+struct Cnt {
+  uint32_t v[NUM_COUNTERS];
+};
+
+// Slab test of one box against [t_min, t_far]; returns hit flag and entry distance.
+template <typename R>
+__device__ __forceinline__ bool slab(const Ray<R>& r, R lox, R loy, R loz, R hix, R hiy, R hiz,
+                                     R t_min, R t_far, R& tn) {
+  R x0 = (lox - r.o.x) * r.inv.x, x1 = (hix - r.o.x) * r.inv.x;
+  R y0 = (loy - r.o.y) * r.inv.y, y1 = (hiy - r.o.y) * r.inv.y;
+  R z0 = (loz - r.o.z) * r.inv.z, z1 = (hiz - r.o.z) * r.inv.z;
+  R nx = M<R>::fmin(x0, x1), fx = M<R>::fmax(x0, x1);
+  R ny = M<R>::fmin(y0, y1), fy = M<R>::fmax(y0, y1);
+  R nz = M<R>::fmin(z0, z1), fz = M<R>::fmax(z0, z1);
+  tn = M<R>::fmax(M<R>::fmax(nx, ny), M<R>::fmax(nz, t_min));
+  R tf = M<R>::fmin(M<R>::fmin(fx, fy), fz);
+  // widen the exit by a few ulps so rounding never drops a box the exact ray touches
+  tf = M<R>::fmin(tf * M<R>::slab_widen(), t_far);
+  return tn <= tf;
+}
+
+// The sphere quadratic in a cancellation-free form.
+// Same acceptance rule as Sphere.hit (Hittable.scala:40-47): discriminant > 0,
+// the near root if it lies in (t_min, t_max), else the far root.
+template <typename R>
+struct SphereSolve {
+  V3<R> cen, l;  // centre; offset of the ray's closest-approach point from the centre
+  R rad, t1, t2; // radius; near and far root
+  R s;           // sqrt(disc)/|d|^2: the roots are t_closest -/+ s
+  bool big;
+};
+template <typename R>
+__device__ __forceinline__ bool sphere_solve(const Scene& sc, const Ray<R>& ray, uint32_t kind,
+                                             uint32_t idx, SphereSolve<R>& o) {
+  typename M<R>::R4 s = load_r4<R>(sc, sc.L.sph, idx);
+  o.cen = mk<R>(s.x, s.y, s.z);
+  o.rad = s.w;
+  o.big = kind == KIND_BIG_SPHERE;
+  V3<R> oc = ray.o - o.cen;
+  R hb = dot(oc, ray.d);
+  o.l = oc - (hb * ray.inv_a) * ray.d;
+  const R r2 = o.rad * o.rad;
+  R c;
+  if (o.big) {
+    R K = *(const R*)(sc.base + sc.L.sph_k + idx * (uint32_t)sizeof(R));
+    c = ray.oo - (R)2 * dot(ray.o, o.cen) + K;
+  } else {
+    c = dot(oc, oc) - r2;
+  }
+  // two forms of the discriminant: from the closest-approach offset (accurate when
+  // the origin is far from the sphere compared with its radius) or b^2 - a c
+  // (accurate when the origin is on or near the surface)
+  const R disc = (c > (R)3 * r2) ? ray.a * (r2 - dot(o.l, o.l)) : hb * hb - ray.a * c;
+  if (!(disc > (R)0)) return false;
+  R sq = M<R>::sqrt(disc);
+  R q = -(hb + M<R>::copysign(sq, hb));
+  R root_a = q * ray.inv_a, root_b = c * M<R>::rcp(q);
+  o.t1 = M<R>::fmin(root_a, root_b);
+  o.t2 = M<R>::fmax(root_a, root_b);
+  o.s = sq * ray.inv_a;
+  return true;
+}
+
+template <typename R>
+struct RectGeom {
+  R a0, a1, b0, b1, k;
+};
+template <typename R>
+__device__ __forceinline__ RectGeom<R> load_rect(const Scene& sc, uint32_t idx) {
+  typename M<R>::R4 r0 = load_r4<R>(sc, sc.L.rect, idx * 2u);
+  R k = *(const R*)(sc.base + sc.L.rect + (idx * 8u + 4u) * (uint32_t)sizeof(R));
+  RectGeom<R> g;
+  g.a0 = r0.x; g.a1 = r0.y; g.b0 = r0.z; g.b1 = r0.w; g.k = k;
+  return g;
+}
+// components of v along the rect's (a, b, k) axes: XY -> (x,y,z), XZ -> (x,z,y), YZ -> (y,z,x)
+template <typename R>
+__device__ __forceinline__ void rect_axes(uint32_t kind, V3<R> v, R& a, R& b, R& k) {
+  a = (kind == KIND_YZRECT) ? v.y : v.x;
+  b = (kind == KIND_XYRECT) ? v.y : v.z;
+  k = (kind == KIND_XYRECT) ? v.z : ((kind == KIND_XZRECT) ? v.y : v.x);
+}
+
+template <typename R>
+struct TriGeom {
+  V3<R> A, e1, e2, n;
+};
+template <typename R>
+__device__ __forceinline__ TriGeom<R> load_tri(const Scene& sc, uint32_t idx) {
+  typename M<R>::R4 q0 = load_r4<R>(sc, sc.L.tri, idx * 3u);
+  typename M<R>::R4 q1 = load_r4<R>(sc, sc.L.tri, idx * 3u + 1u);
+  typename M<R>::R4 q2 = load_r4<R>(sc, sc.L.tri, idx * 3u + 2u);
+  TriGeom<R> g;
+  g.A = mk<R>(q0.x, q0.y, q0.z);
+  g.e1 = mk<R>(q0.w, q1.x, q1.y);
+  g.e2 = mk<R>(q1.z, q1.w, q2.x);
+  g.n = mk<R>(q2.y, q2.z, q2.w);
+  return g;
+}
+// Triangle.hit (Hittable.scala:97-113) with edges and normal precomputed
+template <typename R>
+__device__ __forceinline__ void tri_solve(const TriGeom<R>& g, const Ray<R>& ray, R& det, R& t, R& u,
+                                          R& v) {
+  V3<R> ao = ray.o - g.A;
+  V3<R> dao = cross(ao, ray.d);
+  det = -dot(ray.d, g.n);
+  R inv_det = M<R>::rcp(det);
+  t = dot(ao, g.n) * inv_det;
+  u = dot(g.e2, dao) * inv_det;
+  v = -dot(g.e1, dao) * inv_det;
+}
+
+// One traversal step of one lane: an inner node (two child boxes) or a leaf
+// (one primitive), then advance to the next reference (descend or pop).
+template <typename R, bool CNT>
+__device__ __forceinline__ void trav_step(const Scene& sc, const Ray<R>& ray, Trav<R>& tv,
+                                          uint32_t* stack_lane, R t_min, Cnt& cnt) {
+  constexpr uint32_t BT = M<R>::BT;
+  const uint32_t cur = tv.cur;
+  uint32_t next = REF_EMPTY;
+  bool need_pop = true;
+  if (!(cur & REF_LEAF)) {
+    R b[12];
+    uint32_t cc;
+    load_node<R>(sc, cur, b, cc);
+    R tn0, tn1;
+    bool h0 = slab<R>(ray, b[0], b[1], b[2], b[3], b[4], b[5], t_min, tv.best_t, tn0);
+    bool h1 = slab<R>(ray, b[6], b[7], b[8], b[9], b[10], b[11], t_min, tv.best_t, tn1);
+    uint32_t c0 = cc & 0xFFFFu, c1 = cc >> 16;
+    if (CNT) cnt.v[CTR_BOX] += 2;
+    if (h0 && h1) {
+      bool swp = tn1 < tn0;
+      uint32_t nearc = swp ? c1 : c0, farc = swp ? c0 : c1;
+      R tfar = swp ? tn0 : tn1;
+      uint32_t e = (__float_as_uint(M<R>::to_float_down(tfar)) & 0xFFFF0000u) | farc;
+      stack_lane[tv.sp * BT] = e;
+      tv.sp++;
+      next = nearc;
+      need_pop = false;
+    } else if (h0 || h1) {
+      next = h0 ? c0 : c1;
+      need_pop = false;
+    }
+  } else {
+    const uint32_t kind = (cur >> REF_KIND_SHIFT) & 7u, idx = cur & REF_INDEX_MASK;
+    if (kind == KIND_SPHERE || kind == KIND_BIG_SPHERE) {
+      if (CNT) cnt.v[CTR_SPHERE]++;
+      SphereSolve<R> ss;
+      if (sphere_solve<R>(sc, ray, kind, idx, ss)) {
+        R t = (ss.t1 > t_min) ? ss.t1 : ss.t2;
+        if (t > t_min && t < tv.best_t) { tv.best_t = t; tv.best_ref = cur; }
+      }
+    } else if (kind == KIND_TRIANGLE) {
+      if (CNT) cnt.v[CTR_TRI]++;
+      TriGeom<R> g = load_tri<R>(sc, idx);
+      R det, t, u, v;
+      tri_solve<R>(g, ray, det, t, u, v);
+      R w = (R)1 - u - v;
+      if (det > (R)1e-6 && t >= t_min && t < tv.best_t && u >= (R)0 && v >= (R)0 && w >= (R)0) {
+        tv.best_t = t;
+        tv.best_ref = cur;
+      }
+    } else {  // XY / XZ / YZ rect, Hittable.scala:55-92
+      if (CNT) cnt.v[CTR_RECT]++;
+      RectGeom<R> g = load_rect<R>(sc, idx);
+      R oa, ob, ok, da, db, dk;
+      rect_axes<R>(kind, ray.o, oa, ob, ok);
+      rect_axes<R>(kind, ray.d, da, db, dk);
+      R t = (g.k - ok) * M<R>::rcp(dk);
+      R a = oa + t * da, bb = ob + t * db;
+      if (t >= t_min && t < tv.best_t && a >= g.a0 && a <= g.a1 && bb >= g.b0 && bb <= g.b1) {
+        tv.best_t = t;
+        tv.best_ref = cur;
+      }
+    }
+  }
+  if (need_pop) {
+    next = REF_EMPTY;
+    while (tv.sp > 0) {
+      tv.sp--;
+      uint32_t e = stack_lane[tv.sp * BT];
+      R tn = (R)__uint_as_float(e & 0xFFFF0000u);
+      if (tn < tv.best_t) {
+        next = e & 0xFFFFu;
+        break;
+      }
+    }
+  }
+  tv.cur = next;
+}
+
+// ---------------------------------------------------------------------------
+// hit geometry, textures, materials
+// ---------------------------------------------------------------------------
+template <typename R>
+struct HitGeom {
+  uint32_t kind, idx, meta;
+  V3<R> p;      // Hit.position (Hittable.scala:5)
+  V3<R> n_out;  // outward_normal as the primitive reports it
+};
+
+template <typename R>
+__device__ __forceinline__ HitGeom<R> hit_geometry(const Scene& sc, const Ray<R>& ray, R t,
+                                                   uint32_t ref) {
+  HitGeom<R> h;
+  h.kind = (ref >> REF_KIND_SHIFT) & 7u;
+  h.idx = ref & REF_INDEX_MASK;
+  h.p = ray.o + t * ray.d;
+  if (h.kind == KIND_SPHERE || h.kind == KIND_BIG_SPHERE) {
+    // outward normal (p - center)/radius (Hittable.scala:44).  For an ordinary
+    // sphere p - center is rebuilt from the closest-approach offset and the
+    // half-chord, both of the size of the radius, so its error scales with the
+    // radius and not with the distance the ray travelled; the hit point is then
+    // center + that vector.
+    SphereSolve<R> ss;
+    sphere_solve<R>(sc, ray, h.kind, h.idx, ss);
+    V3<R> pc;
+    if (ss.big) {
+      pc = h.p - ss.cen;
+    } else {
+      // one re-orthogonalisation of l against d removes the along-ray error that the
+      // rounding of the closest-approach parameter left in it
+      const V3<R> l = ss.l - (dot(ss.l, ray.d) * ray.inv_a) * ray.d;
+      const bool near_root = M<R>::fabs(t - ss.t1) <= M<R>::fabs(t - ss.t2);
+      pc = l + (near_root ? -ss.s : ss.s) * ray.d;
+      h.p = ss.cen + pc;
+    }
+    h.n_out = M<R>::rcp(ss.rad) * pc;
+    h.meta = load_u32(sc, sc.L.meta_sph, h.idx);
+  } else if (h.kind == KIND_TRIANGLE) {
+    typename M<R>::R4 q2 = load_r4<R>(sc, sc.L.tri, h.idx * 3u + 2u);
+    h.n_out = mk<R>(q2.y, q2.z, q2.w);  // raw cross product, Hittable.scala:100,111
+    h.meta = load_u32(sc, sc.L.meta_tri, h.idx);
+  } else {
+    // every rect reports +z (Hittable.scala:62, 76, 90)
+    h.n_out = mk<R>((R)0, (R)0, (R)1);
+    // the hit point lies on the plane: pin that coordinate so that rounding of
+    // o + t*d cannot put the next ray's origin off the rect
+    R k = *(const R*)(sc.base + sc.L.rect + (h.idx * 8u + 4u) * (uint32_t)sizeof(R));
+    if (h.kind == KIND_XYRECT) h.p.z = k;
+    else if (h.kind == KIND_XZRECT) h.p.y = k;
+    else h.p.x = k;
+    h.meta = load_u32(sc, sc.L.meta_rect, h.idx);
+  }
+  return h;
+}
+
+// Hit.uv, evaluated only when an Image texture asks for it.
+template <typename R>
+__device__ __forceinline__ void hit_uv(const Scene& sc, const Ray<R>& ray, const HitGeom<R>& h, R& u,
+                                    R& v) {
+  if (h.kind == KIND_SPHERE || h.kind == KIND_BIG_SPHERE) {
+    // Sphere.get_uv of the NEAR root's point, whichever root was accepted
+    // (Hittable.scala:44, 46 both pass r.at(t1))
+    SphereSolve<R> ss;
+    sphere_solve<R>(sc, ray, h.kind, h.idx, ss);
+    V3<R> q = M<R>::rcp(ss.rad) * (ss.big ? (ray.o + ss.t1 * ray.d) - ss.cen : ss.l - ss.s * ray.d);
+    const R PI = (R)3.14159265358979323846;
+    R phi = M<R>::atan2(q.z, q.x);
+    R theta = M<R>::asin(M<R>::fmin(M<R>::fmax(q.y, (R)-1), (R)1));
+    u = (R)1 - (phi + PI) / ((R)2 * PI);
+    v = (theta + PI / (R)2) / PI;
+  } else if (h.kind == KIND_TRIANGLE) {
+    TriGeom<R> g = load_tri<R>(sc, h.idx);
+    R det, t;
+    tri_solve<R>(g, ray, det, t, u, v);
+  } else {
+    RectGeom<R> g = load_rect<R>(sc, h.idx);
+    R a, b, k;
+    rect_axes<R>(h.kind, h.p, a, b, k);
+    u = (a - g.a0) / (g.a1 - g.a0);
+    v = (b - g.b0) / (g.b1 - g.b0);
+  }
+}
+
+// Perlin.noise (Texture.scala:44-76)
+template <typename R>
+__device__ __forceinline__ R perlin_noise(const Scene& sc, uint32_t table, V3<R> p) {
+  const uint8_t* tb = sc.base + sc.L.perlin + table * sc.L.perlin_stride;
+  const uint8_t* perm = tb + 256u * 4u * (uint32_t)sizeof(R);
+  R fx = M<R>::floor(p.x), fy = M<R>::floor(p.y), fz = M<R>::floor(p.z);
+  R u = p.x - fx, v = p.y - fy, w = p.z - fz;
+  int i = (int)fx, j = (int)fy, k = (int)fz;
+  R uu = u * u * ((R)3 - (R)2 * u);
+  R vv = v * v * ((R)3 - (R)2 * v);
+  R ww = w * w * ((R)3 - (R)2 * w);
+  R sum = 0;
+#pragma unroll
+  for (int di = 0; di < 2; ++di)
+#pragma unroll
+    for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+      for (int dk = 0; dk < 2; ++dk) {
+        uint32_t g = (uint32_t)perm[(i + di) & 255] ^ (uint32_t)perm[256 + ((j + dj) & 255)] ^
+                     (uint32_t)perm[512 + ((k + dk) & 255)];
+        typename M<R>::R4 c = *(const typename M<R>::R4*)(tb + g * (uint32_t)(4 * sizeof(R)));
+        R wx = di ? uu : (R)1 - uu, wy = dj ? vv : (R)1 - vv, wz = dk ? ww : (R)1 - ww;
+        sum += wx * wy * wz * (c.x * (u - (R)di) + c.y * (v - (R)dj) + c.z * (w - (R)dk));
+      }
+  return sum;
+}
+// Perlin.turb, depth 7 (Texture.scala:78-88)
+template <typename R>
+__device__ __forceinline__ R perlin_turb(const Scene& sc, uint32_t table, V3<R> p) {
+  R accum = 0, weight = 1;
+  for (int i = 0; i < 7; ++i) {
+    accum += weight * perlin_noise<R>(sc, table, p);
+    p = (R)2 * p;
+    weight *= (R)0.5;
+  }
+  return M<R>::fabs(accum);
+}
+
+// texture(uv, p) (Texture.scala:13, 21-25, 90, 98-107)
+template <typename R, bool CNT>
+__device__ __forceinline__ V3<R> texture_eval(const Scene& sc, const uint32_t* __restrict__ texels,
+                                              uint32_t tex, const Ray<R>& ray, const HitGeom<R>& h,
+                                              Cnt& cnt) {
+  for (;;) {
+    typename M<R>::R4 t = load_r4<R>(sc, sc.L.tex, tex);
+    uint32_t w3 = M<R>::bits_lo(t.w);
+    uint32_t kind = w3 & 3u;
+    if (CNT) cnt.v[CTR_TEX0 + kind]++;
+    if (kind == 0u) return mk<R>(t.x, t.y, t.z);
+    if (kind == 1u) {  // Checker
+      R sines = M<R>::sin(t.x * h.p.x) * M<R>::sin(t.x * h.p.y) * M<R>::sin(t.x * h.p.z);
+      tex = (sines < (R)0) ? ((w3 >> 2) & 0x7FFFu) : (w3 >> 17);
+      continue;
+    }
+    if (kind == 2u) {  // Perlin
+      R g = (R)0.5 * ((R)1 + M<R>::sin(t.x * h.p.z + (R)10 * perlin_turb<R>(sc, (w3 >> 2) & 0x7FFFu, h.p)));
+      return mk<R>(g, g, g);
+    }
+    // Image: nearest texel, no linearisation (Texture.scala:98-107, Vec3.scala:36-40)
+    R u, v;
+    hit_uv<R>(sc, ray, h, u, v);
+    const uint32_t* im = (const uint32_t*)(sc.base + sc.L.images) + ((w3 >> 2) & 0x7FFFu) * 4u;
+    int width = (int)im[0], height = (int)im[1];
+    uint64_t off = (uint64_t)im[2] | ((uint64_t)im[3] << 32);
+    R uc = M<R>::fmin(M<R>::fmax(u, (R)0), (R)1);
+    R vc = (R)1 - M<R>::fmin(M<R>::fmax(v, (R)0), (R)1);
+    int ii = min(max((int)(uc * (R)width), 0), width - 1);
+    int jj = min(max((int)(vc * (R)height), 0), height - 1);
+    uint32_t rgb = texels[off + (uint64_t)jj * (uint64_t)width + (uint64_t)ii];
+    const R s = (R)(1.0 / 255.0);
+    return mk<R>((R)((rgb >> 16) & 0xFFu) * s, (R)((rgb >> 8) & 0xFFu) * s, (R)(rgb & 0xFFu) * s);
+  }
+}
+
+// Vec3.random_unit_vector (Vec3.scala:29-34) from two uniforms
+template <typename R>
+__device__ __forceinline__ V3<R> unit_vector_from(R u0, R u1) {
+  R z = (R)2 * u1 - (R)1;
+  R r = M<R>::sqrt((R)1 - z * z);
+  R s, c;
+  M<R>::sincos2pi(u0, s, c);
+  return mk<R>(r * c, r * s, z);
+}
+
+// material.scatter + material.emit for the closest hit (Material.scala:9-55,
+// Camera.scala:29-33).  Returns true when the path continues with `ray`
+// replaced by the scattered ray and T multiplied by the attenuation.
+template <typename R, bool CNT>
+__device__ __forceinline__ bool shade_hit(const Scene& sc, const RenderArgs& A, Ray<R>& ray,
+                                          const Trav<R>& tv, V3<R>& T, V3<R>& sum, uint32_t pixel,
+                                          uint32_t sample, uint32_t bounce, Cnt& cnt) {
+  HitGeom<R> h = hit_geometry<R>(sc, ray, tv.best_t, tv.best_ref);
+  typename M<R>::R4 m = load_r4<R>(sc, sc.L.mat, h.meta >> META_MAT_SHIFT);
+  const uint32_t m0 = M<R>::bits_lo(m.x);
+  const uint32_t mkind = m0 & 15u, tex = m0 >> 4;
+  const R param = m.y;
+  if (CNT) cnt.v[CTR_SHADE0 + mkind]++;
+  const bool front = dot(ray.d, h.n_out) < (R)0;          // Hit.front_face
+  const V3<R> n = front ? h.n_out : -h.n_out;             // Hit.normal (not normalised)
+  V3<R> col = texture_eval<R, CNT>(sc, A.texels, tex, ray, h, cnt);
+  if (mkind == 3u) {  // Emission: never scatters, emits on both faces
+    sum = sum + T * (param * col);
+    return false;
+  }
+  uint32_t rnd[4];
+  philox4x32_10(pixel, sample, bounce, 0u, A.seed_lo, A.seed_hi, rnd);
+  V3<R> dir;
+  if (mkind == 0u) {  // Diffuse
+    dir = n + unit_vector_from<R>(u01<R>(rnd[0]), u01<R>(rnd[1]));
+  } else if (mkind == 1u) {  // Glossy
+    V3<R> ud = M<R>::rsqrt(ray.a) * ray.d;
+    V3<R> refl = ud - ((R)2 * dot(ud, n)) * n;
+    V3<R> ball = M<R>::cbrt(u01<R>(rnd[2])) * unit_vector_from<R>(u01<R>(rnd[0]), u01<R>(rnd[1]));
+    dir = refl + param * ball;
+    if (!(dot(dir, n) > (R)0)) return false;  // absorbed, emit = 0
+  } else {  // Glass
+    V3<R> ud = M<R>::rsqrt(ray.a) * ray.d;
+    R eta = front ? M<R>::rcp(param) : param;
+    R cos_theta = M<R>::fmin(-dot(ud, n), (R)1);
+    R sin_theta = M<R>::sqrt((R)1 - cos_theta * cos_theta);
+    bool reflect_it = eta * sin_theta > (R)1;
+    if (!reflect_it) {
+      R r0 = ((R)1 - eta) / ((R)1 + eta);
+      R r1 = r0 * r0;
+      R x = (R)1 - cos_theta;
+      R x2 = x * x;
+      R sch = r1 + ((R)1 - r1) * (x2 * x2 * x);
+      reflect_it = sch > u01<R>(rnd[0]);
+    }
+    if (reflect_it) {
+      dir = ud - ((R)2 * dot(ud, n)) * n;
+    } else {
+      R ct = -dot(ud, n);
+      V3<R> perp = eta * (ud + ct * n);
+      V3<R> par = (-M<R>::sqrt(M<R>::fabs((R)1 - dot(perp, perp)))) * n;
+      dir = perp + par;
+    }
+  }
+  T = T * col;
+  ray.o = h.p;
+  ray.d = dir;
+  ray_setup<R>(ray);
+  return true;
+}
+
+// Camera.get_ray (Camera.scala:19-23) for sample `sample` of pixel (i, j)
+// (main.scala:88-89).
+template <typename R>
+__device__ __forceinline__ void camera_ray(const RenderArgs& A, const CamDev<R>& cam, Ray<R>& ray,
+                                           uint32_t i, uint32_t j, uint32_t pixel, uint32_t sample) {
+  R xi1 = (R)0.5, xi2 = (R)0.5;
+  V3<R> offset = mk<R>((R)0, (R)0, (R)0);
+  if (A.jitter) {
+    uint32_t rnd[4];
+    philox4x32_10(pixel, sample, 0u, 0u, A.seed_lo, A.seed_hi, rnd);
+    xi1 = u01<R>(rnd[0]);
+    xi2 = u01<R>(rnd[1]);
+    // uniform point of the unit disk, scaled by the lens radius
+    R r = cam.lens_radius * M<R>::sqrt(u01<R>(rnd[2]));
+    R s, c;
+    M<R>::sincos2pi(u01<R>(rnd[3]), s, c);
+    offset = (r * c) * ld3<R>(cam.u) + (r * s) * ld3<R>(cam.v);
+  }
+  R s = ((R)i + xi1) / (R)(A.W - 1);
+  R t = ((R)j + xi2) / (R)(A.H - 1);
+  V3<R> origin = ld3<R>(cam.origin);
+  ray.o = origin + offset;
+  ray.d = ld3<R>(cam.llc) + s * ld3<R>(cam.horizontal) + t * ld3<R>(cam.vertical) - origin - offset;
+  ray_setup<R>(ray);
+}
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void copy_scene_to_lds(uint8_t* lds, const uint8_t* blob, uint32_t bytes,
+                                                  uint32_t nthreads) {
+  const uint4* src = (const uint4*)blob;
+  uint4* dst = (uint4*)lds;
+  for (uint32_t i = threadIdx.x; i < bytes / 16u; i += nthreads) dst[i] = src[i];
+  __syncthreads();
+}
+
+enum : uint32_t { ST_TRAV = 0, ST_WAIT = 1, ST_DEAD = 2, ST_DONE = 3 };
+
+template <typename R, bool CNT>
+__global__ void __launch_bounds__(M<R>::BT) render_kernel(RenderArgs A, CamDev<R> cam) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  constexpr uint32_t BT = M<R>::BT;
+  copy_scene_to_lds(lds, A.blob, A.L.total_bytes, BT);
+  Scene sc;
+  sc.base = lds;
+  sc.L = A.L;
+  uint32_t* stack_lane = (uint32_t*)(lds + A.L.total_bytes) + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t tiles_x = (uint32_t)(A.W + TILE_W - 1) / TILE_W;
+  const uint32_t tiles_y = (uint32_t)(A.H + TILE_H - 1) / TILE_H;
+  const uint32_t n_tiles = tiles_x * tiles_y;
+  const R t_min = (R)0.001;  // Camera.scala:28
+  const V3<R> bg = ld3<R>(cam.background);
+  Cnt cnt;
+  if (CNT) {
+#pragma unroll
+    for (int k = 0; k < NUM_COUNTERS; ++k) cnt.v[k] = 0;
+  }
+
+  for (;;) {
+    uint32_t tile = 0;
+    if (lane == 0) tile = atomicAdd(A.tile_counter, 1u);
+    tile = __shfl(tile, 0);
+    if (tile >= n_tiles) break;
+    const uint32_t px = (tile % tiles_x) * TILE_W + (lane & 7u);
+    const uint32_t py = (tile / tiles_x) * TILE_H + (lane >> 3);
+    const bool valid = px < (uint32_t)A.W && py < (uint32_t)A.H;
+    const uint32_t pixel = py * (uint32_t)A.W + px;
+
+    Ray<R> ray;
+    Trav<R> tv;
+    V3<R> T = mk<R>((R)1, (R)1, (R)1);
+    V3<R> sum = mk<R>((R)0, (R)0, (R)0);
+    uint32_t state = valid ? ST_DEAD : ST_DONE;
+    uint32_t s_next = 0;  // next sample of this pixel to start
+    uint32_t sample = 0, bounce = 0;
+    ray.o = ray.d = ray.inv = mk<R>((R)0, (R)0, (R)0);
+    ray.a = ray.inv_a = ray.oo = (R)0;
+    trav_begin<R>(tv);
+
+    for (;;) {
+      // ---- shade the lanes whose ray is finished --------------------------------
+      if (state == ST_WAIT) {
+        bool cont;
+        if (tv.best_ref == REF_EMPTY) {
+          sum = sum + T * bg;  // case None => background (Camera.scala:34)
+          cont = false;
+        } else {
+          cont = shade_hit<R, CNT>(sc, A, ray, tv, T, sum, pixel, sample, bounce, cnt);
+          // depth exhausted: the next ray_color call returns 0 (Camera.scala:27)
+          if (cont && bounce >= (uint32_t)A.max_depth) cont = false;
+        }
+        if (cont) {
+          bounce++;
+          trav_begin<R>(tv);
+          state = ST_TRAV;
+          if (CNT) cnt.v[CTR_RAYS]++;
+        } else {
+          state = ST_DEAD;
+        }
+      }
+      // ---- start the pixel's next camera path on dead lanes -----------------------
+      if (state == ST_DEAD) {
+        if (s_next < (uint32_t)A.sample_count) {
+          sample = (uint32_t)A.sample_first + s_next;
+          s_next++;
+          camera_ray<R>(A, cam, ray, px, py, pixel, sample);
+          T = mk<R>((R)1, (R)1, (R)1);
+          bounce = 1;
+          trav_begin<R>(tv);
+          state = ST_TRAV;
+          if (CNT) cnt.v[CTR_RAYS]++;
+        } else {
+          state = ST_DONE;
+        }
+      }
+      if (__ballot(state == ST_TRAV) == 0ull) break;  // every lane is DONE
+      // ---- traversal, until enough lanes wait for shading --------------------------
+      for (;;) {
+        if (state == ST_TRAV) {
+          trav_step<R, CNT>(sc, ray, tv, stack_lane, t_min, cnt);
+          if (tv.cur == REF_EMPTY) state = ST_WAIT;
+          if (CNT) cnt.v[CTR_ACTIVE]++;
+        }
+        if (CNT) cnt.v[CTR_STEPS]++;
+        const uint64_t trav = __ballot(state == ST_TRAV);
+        const uint64_t wait = __ballot(state == ST_WAIT);
+        if (trav == 0ull || __popcll(wait) >= A.wait_threshold) break;
+      }
+    }
+    if (valid) {
+      float* out = A.accum + (size_t)pixel * 3u;
+      out[0] += (float)sum.x;
+      out[1] += (float)sum.y;
+      out[2] += (float)sum.z;
+    }
+  }
+  if (CNT && A.counters) {
+#pragma unroll
+    for (int k = 0; k < NUM_COUNTERS; ++k) {
+      // wave reduction, then one atomic per wave
+      uint32_t v = cnt.v[k];
+      unsigned long long tot = v;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+      if (lane == 0) atomicAdd(&A.counters[k], tot);
+    }
+  }
+}
+
+// world.hit(camera ray through the pixel centre, 0.001, +inf) for every pixel.
+template <typename R>
+__global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, CamDev<R> cam) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  constexpr uint32_t BT = M<R>::BT;
+  copy_scene_to_lds(lds, A.blob, A.L.total_bytes, BT);
+  Scene sc;
+  sc.base = lds;
+  sc.L = A.L;
+  uint32_t* stack_lane = (uint32_t*)(lds + A.L.total_bytes) + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t tiles_x = (uint32_t)(A.W + TILE_W - 1) / TILE_W;
+  const uint32_t tiles_y = (uint32_t)(A.H + TILE_H - 1) / TILE_H;
+  const uint32_t tile = blockIdx.x * (BT / 64u) + threadIdx.x / 64u;
+  if (tile >= tiles_x * tiles_y) return;
+  const uint32_t px = (tile % tiles_x) * TILE_W + (lane & 7u);
+  const uint32_t py = (tile / tiles_x) * TILE_H + (lane >> 3);
+  if (px >= (uint32_t)A.W || py >= (uint32_t)A.H) return;
+  const uint32_t pixel = py * (uint32_t)A.W + px;
+
+  RenderArgs ra;
+  ra.jitter = 0;
+  ra.W = A.W;
+  ra.H = A.H;
+  ra.seed_lo = ra.seed_hi = 0;
+  CamDev<R> c = cam;
+  c.lens_radius = (R)0;
+  Ray<R> ray;
+  camera_ray<R>(ra, c, ray, px, py, pixel, 0u);
+  Trav<R> tv;
+  trav_begin<R>(tv);
+  Cnt cnt;
+  while (tv.cur != REF_EMPTY) trav_step<R, false>(sc, ray, tv, stack_lane, (R)0.001, cnt);
+
+  R* t_out = (R*)A.t;
+  R* n_out = (R*)A.normal;
+  if (tv.best_ref == REF_EMPTY) {
+    t_out[pixel] = M<R>::inf();
+    A.prim[pixel] = -1;
+    n_out[pixel * 3u] = n_out[pixel * 3u + 1u] = n_out[pixel * 3u + 2u] = (R)0;
+  } else {
+    HitGeom<R> h = hit_geometry<R>(sc, ray, tv.best_t, tv.best_ref);
+    const bool front = dot(ray.d, h.n_out) < (R)0;
+    const V3<R> n = front ? h.n_out : -h.n_out;
+    t_out[pixel] = tv.best_t;
+    A.prim[pixel] = (int32_t)(h.meta & META_PRIM_MASK);
+    n_out[pixel * 3u] = n.x;
+    n_out[pixel * 3u + 1u] = n.y;
+    n_out[pixel * 3u + 2u] = n.z;
+  }
+}
+
+// mean radiance, Vec3.toRGB (Vec3.scala:82-84: 255 * clamp(sqrt(x), 0, 0.999),
+// truncated; NaN -> 0) and the row flip of img.setRGB(i, H-j-1, ..) (main.scala:93)
+__global__ void resolve_kernel(const float* __restrict__ accum, int32_t W, int32_t H,
+                               float inv_samples, float* __restrict__ rgb_mean,
+                               uint32_t* __restrict__ rgb_packed) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (uint32_t)(W * H)) return;
+  const uint32_t i = p % (uint32_t)W, j = p / (uint32_t)W;
+  uint32_t code = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float m = accum[(size_t)p * 3u + c] * inv_samples;
+    if (rgb_mean) rgb_mean[(size_t)p * 3u + c] = m;
+    double g = ::sqrt((double)m);
+    g = ::fmin(::fmax(g, 0.0), 0.999);  // fmax(NaN, 0) = 0, the value NaN.toInt gives
+    code = (code << 8) | (uint32_t)(int)(255.0 * g);
+  }
+  if (rgb_packed) rgb_packed[(size_t)((uint32_t)H - 1u - j) * (uint32_t)W + i] = code;
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+uint32_t lds_bytes_needed(const SceneLayout& L, int precision) {
+  const uint32_t bt = precision == 0 ? M<float>::BT : M<double>::BT;
+  return L.total_bytes + bt * 4u * (L.depth + 1u);
+}
+
+template <typename K>
+static hipError_t allow_big_lds(K kernel, uint32_t lds_bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+}
+
+template <typename K>
+static int blocks_per_cu(K kernel, int threads, uint32_t lds_bytes) {
+  if (allow_big_lds(kernel, lds_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kernel), threads,
+                                                   lds_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int render_blocks_per_cu(int precision, bool counters, uint32_t lds_bytes) {
+  if (precision == 0)
+    return counters ? blocks_per_cu(render_kernel<float, true>, M<float>::BT, lds_bytes)
+                    : blocks_per_cu(render_kernel<float, false>, M<float>::BT, lds_bytes);
+  return counters ? blocks_per_cu(render_kernel<double, true>, M<double>::BT, lds_bytes)
+                  : blocks_per_cu(render_kernel<double, false>, M<double>::BT, lds_bytes);
+}
+
+hipError_t launch_render(int precision, bool counters, const RenderArgs& a, const void* cam,
+                         int grid_blocks, uint32_t lds_bytes, hipStream_t stream) {
+  if (precision == 0) {
+    const CamDev<float>& c = *static_cast<const CamDev<float>*>(cam);
+    if (counters)
+      hipLaunchKernelGGL((render_kernel<float, true>), dim3(grid_blocks), dim3(M<float>::BT), lds_bytes,
+                         stream, a, c);
+    else
+      hipLaunchKernelGGL((render_kernel<float, false>), dim3(grid_blocks), dim3(M<float>::BT), lds_bytes,
+                         stream, a, c);
+  } else {
+    const CamDev<double>& c = *static_cast<const CamDev<double>*>(cam);
+    if (counters)
+      hipLaunchKernelGGL((render_kernel<double, true>), dim3(grid_blocks), dim3(M<double>::BT),
+                         lds_bytes, stream, a, c);
+    else
+      hipLaunchKernelGGL((render_kernel<double, false>), dim3(grid_blocks), dim3(M<double>::BT),
+                         lds_bytes, stream, a, c);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_first_hit(int precision, const FirstHitArgs& a, const void* cam, uint32_t lds_bytes,
+                            hipStream_t stream) {
+  const uint32_t tiles = (uint32_t)((a.W + TILE_W - 1) / TILE_W) * (uint32_t)((a.H + TILE_H - 1) / TILE_H);
+  if (precision == 0) {
+    hipError_t e = allow_big_lds(first_hit_kernel<float>, lds_bytes);
+    if (e != hipSuccess) return e;
+    const uint32_t wpb = M<float>::BT / 64;
+    hipLaunchKernelGGL((first_hit_kernel<float>), dim3((tiles + wpb - 1) / wpb), dim3(M<float>::BT),
+                       lds_bytes, stream, a, *static_cast<const CamDev<float>*>(cam));
+  } else {
+    hipError_t e = allow_big_lds(first_hit_kernel<double>, lds_bytes);
+    if (e != hipSuccess) return e;
+    const uint32_t wpb = M<double>::BT / 64;
+    hipLaunchKernelGGL((first_hit_kernel<double>), dim3((tiles + wpb - 1) / wpb), dim3(M<double>::BT),
+                       lds_bytes, stream, a, *static_cast<const CamDev<double>*>(cam));
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_resolve(const float* accum, int32_t W, int32_t H, float inv_samples, float* rgb_mean,
+                          uint32_t* rgb_packed, hipStream_t stream) {
+  const uint32_t n = (uint32_t)(W * H);
+  hipLaunchKernelGGL(resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, accum, W, H,
+                     inv_samples, rgb_mean, rgb_packed);
+  return hipGetLastError();
+}
+
+}  // namespace ht

@@ -1,0 +1,53 @@
+"""Minimal device-buffer helper for the GPU tests: hipMalloc / hipMemcpy through
+ctypes on the HIP runtime that libhiptrace.so already loaded (no torch needed)."""
+import ctypes as C
+
+import numpy as np
+
+_hip = None
+
+
+def hip():
+    global _hip
+    if _hip is None:
+        from raytracing_amd import lib
+
+        lib.load()  # pulls in libamdhip64
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        _hip.hipFree.argtypes = [C.c_void_p]
+        _hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return _hip
+
+
+class DeviceBuffer:
+    """A zero-initialised float32 device array."""
+
+    def __init__(self, n_floats: int):
+        self.n = n_floats
+        self.ptr = C.c_void_p()
+        assert hip().hipMalloc(C.byref(self.ptr), n_floats * 4) == 0
+        assert hip().hipMemset(self.ptr, 0, n_floats * 4) == 0
+        assert hip().hipDeviceSynchronize() == 0
+
+    @property
+    def address(self) -> int:
+        return self.ptr.value
+
+    def to_host(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.float32)
+        assert hip().hipDeviceSynchronize() == 0
+        assert hip().hipMemcpy(out.ctypes.data_as(C.c_void_p), self.ptr, self.n * 4, 2) == 0  # D2H
+        return out
+
+    def free(self):
+        if self.ptr:
+            hip().hipFree(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,40 @@
+"""First-hit error analysis fp32 device vs oracle (development aid)."""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raytracing_amd.scene import load_scene, flatten
+from raytracing_amd import lib as ht
+import oracle
+SC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/golden/scenes")
+names = sys.argv[1:] or ["scene", "dragon", "cornell", "random", "perlin", "checker", "light"]
+for name in names:
+    cam, world = load_scene(f"{SC}/{name}.json")
+    flat = flatten(world)
+    osc = oracle.OracleScene(flat, bvh_seed=1)
+    W, H = 640, 360
+    d = 2.5e-7 * W
+    base = osc.first_hit(cam, W, H)
+    pert = [osc.first_hit(cam, W, H, off=(0.5 + dx, 0.5 + dy)) for dx, dy in ((d, 0), (-d, 0), (0, d), (0, -d))]
+    stable = np.ones((H, W), bool)
+    sens = np.zeros((H, W))
+    for p in pert:
+        stable &= p["prim_id"] == base["prim_id"]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            sens = np.maximum(sens, np.where(base["prim_id"] >= 0, np.abs(p["t"] - base["t"]) / np.abs(base["t"]), 0))
+    with ht.Scene(flat) as s:
+        fh = s.first_hit(cam, W, H, precision=0)
+    hit = base["prim_id"] >= 0
+    idm = fh["prim_id"] != base["prim_id"]
+    both = hit & ~idm
+    terr = np.zeros((H, W)); nerr = np.zeros((H, W))
+    terr[both] = np.abs(fh["t64"][both] - base["t"][both]) / np.abs(base["t"][both])
+    nerr[both] = np.linalg.norm(fh["normal64"][both] - base["normal"][both], axis=-1) / np.linalg.norm(base["normal"][both], axis=-1)
+    good = both & stable & (sens <= 2.5e-6)
+    print(f"{name:8s} hits={hit.sum()} id_mismatch={idm.sum()} (on stable: {(idm & stable).sum()}) unstable={(~stable).sum()} illcond={(hit & (sens > 2.5e-6)).sum()} "
+          f"t: max_all={terr.max():.2e} max_good={terr[good].max() if good.any() else 0:.2e} p99.9={np.percentile(terr[both], 99.9):.2e} "
+          f"n: max_all={nerr.max():.2e} max_good={nerr[good].max() if good.any() else 0:.2e} p99.9={np.percentile(nerr[both], 99.9):.2e}", flush=True)
+    # worst good pixels
+    idx = np.argsort((nerr * good).ravel())[-3:]
+    for k in idx:
+        j, i = divmod(int(k), W)
+        print(f"    worst-n good pixel ({i},{j}) prim={base['prim_id'][j,i]} kind={flat.prim_type[base['prim_id'][j,i]]} t={base['t'][j,i]:.4f} terr={terr[j,i]:.2e} nerr={nerr[j,i]:.2e} sens={sens[j,i]:.2e}")

@@ -1,0 +1,34 @@
+"""Throughput probe used while developing (not part of the test suite)."""
+import sys, time, os, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raytracing_amd.scene import load_scene, flatten
+from raytracing_amd import lib as ht, _abi as A
+
+SC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/golden/scenes")
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("scenes", nargs="*", default=["dragon", "random", "cornell"])
+ap.add_argument("--w", type=int, default=1920); ap.add_argument("--h", type=int, default=1080)
+ap.add_argument("--spp", type=int, default=64); ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--wait", type=int, nargs="*", default=[24]); ap.add_argument("--bpc", type=int, default=2)
+ap.add_argument("--counters", type=int, default=1); ap.add_argument("--prec", type=int, default=0)
+a = ap.parse_args()
+ht.set_option("max_blocks_per_cu", a.bpc)
+for name in a.scenes:
+    cam, world = load_scene(f"{SC}/{name}.json")
+    flat = flatten(world)
+    W, H = (1024, 1024) if name == "cornell" and a.w == 1920 else (a.w, a.h)
+    with ht.Scene(flat) as s:
+        s.render(cam, W, H, 4, precision=a.prec)  # warm-up
+        for wt in a.wait:
+            ht.set_option("wait_threshold", wt)
+            r = s.render(cam, W, H, a.spp, precision=a.prec, batch=a.batch, seed=1)
+            st = r["stats"]
+            line = f"{name:8s} {W}x{H}x{a.spp} wait={wt} kernel_s={st['seconds_kernel']:.4f} Msamples/s={st['samples']/st['seconds_kernel']/1e6:.1f} mean={r['rgb'].mean():.5f}"
+            if a.counters:
+                r2 = s.render(cam, W, H, min(a.spp, 16), precision=a.prec, batch=a.batch, seed=1, collect_counters=1)
+                c = r2["stats"]; ns = c["samples"]
+                flops = 40 * ns + 18 * c["n_box"] + 25 * c["n_sphere"] + 12 * c["n_rect"] + 38 * c["n_tri"] + 40 * c["n_shade"][0] + 50 * c["n_shade"][1] + 65 * c["n_shade"][2] + 700 * c["n_tex"][2] + 8 * c["n_tex"][3]
+                line += f" rays/s={c['n_rays']/ns:.2f} box/ray={c['n_box']/c['n_rays']:.1f} prim/ray={(c['n_sphere']+c['n_rect']+c['n_tri'])/c['n_rays']:.2f} flop/sample={flops/ns:.0f} util={c['n_active']/max(1,c['n_steps']):.3f} TFLOPs={flops/ns*st['samples']/st['seconds_kernel']/1e12:.2f}"
+            print(line, flush=True)
