@@ -6,8 +6,9 @@ intersect / shade loop on scenes/dragon.json at 1920x1080, 1024 spp.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one whole frame: every rank path-traces its share of the
-samples-per-pixel range for all pixels into a device buffer of radiance sums,
-the buffers are summed onto rank 0 with one reduce (RCCL over xGMI), and rank 0
+samples-per-pixel range for all pixels into a device buffer of radiance sums
+(int64, 32.32 fixed point), the buffers are summed onto rank 0 with one reduce
+(RCCL over xGMI), and rank 0
 resolves the frame (mean, tone-map, row flip) on the GPU.  The frame is fixed
 while N grows (strong scaling).  Rank 0 prints ONE JSON line.
 
@@ -127,7 +128,7 @@ def main():
     scene = ht.Scene(flat, device=local_rank)
     first, count = shard_samples(spp, rank, world)
 
-    accum = torch.zeros(H * W * 3, dtype=torch.float32, device=dev)
+    accum = torch.zeros(H * W * 3, dtype=torch.int64, device=dev)  # 32.32 fixed-point radiance sums
     rgb_mean = torch.empty(H * W * 3, dtype=torch.float32, device=dev)
     packed = torch.empty(H * W, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream

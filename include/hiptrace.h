@@ -163,6 +163,11 @@ typedef struct ht_stats {
   int64_t n_tex[4];       /* texture evaluations per HT_TEX_* (leaf or checker)     */
   int64_t n_steps;        /* wave-loop iterations x 64 (lane slots offered)         */
   int64_t n_active;       /* lane slots that held a live path                       */
+  int64_t n_shade_rounds; /* wave-level shading rounds                               */
+  int64_t n_regen_rounds; /* wave-level camera-path start rounds                     */
+  int64_t n_miss;         /* paths that left the scene (background)                  */
+  int64_t cyc_trav, cyc_shade, cyc_regen; /* wave cycles spent per phase, summed over waves */
+  double shader_clock_mhz; /* in-kernel clock: s_memtime ticks per 100 MHz s_memrealtime tick */
 } ht_stats;
 
 typedef struct ht_scene ht_scene; /* opaque */
@@ -192,25 +197,31 @@ void ht_scene_destroy(ht_scene* scene);
 int ht_render(ht_scene* scene, const ht_camera* camera, const ht_render_params* params,
               float* rgb_linear, uint32_t* rgb_packed, ht_stats* stats_out);
 
+/* Radiance sums are signed 32.32 fixed point (value = sum * 2^-32).  Integer
+ * sums commute, so a frame is bit-identical however it is cut into batches,
+ * launches, calls or GPUs. */
+#define HT_ACCUM_ONE 4294967296.0
+
 /* Multi-device building block: add this call's radiance SUMS (not means) into
- * `accum_dev`, a DEVICE buffer of width*height*3 floats on the scene's device
- * (row 0 = bottom).  `stream` is a hipStream_t (NULL: default stream).  The call
- * returns after the work is enqueued and, if stats_out is non-NULL, complete.
- * The caller reduces the buffers of all ranks (RCCL reduce over xGMI) and then
- * calls ht_resolve on the root. */
+ * `accum_dev`, a DEVICE buffer of width*height*3 int64 on the scene's device
+ * (row 0 = bottom; the caller zeroes it before the first call).  `stream` is a
+ * hipStream_t (NULL: default stream).  The call returns after the work is enqueued
+ * and, if stats_out is non-NULL, complete.  The caller reduces the buffers of all
+ * ranks (RCCL reduce(sum) of int64 over xGMI) and then calls ht_resolve on the
+ * root. */
 int ht_render_accumulate(ht_scene* scene, const ht_camera* camera,
-                         const ht_render_params* params, float* accum_dev, void* stream,
+                         const ht_render_params* params, int64_t* accum_dev, void* stream,
                          ht_stats* stats_out);
 
 /* Divide a DEVICE sum buffer by total_samples and write the host pictures as
  * ht_render does (mean, then Vec3.toRGB + row flip). */
-int ht_resolve(ht_scene* scene, const float* accum_dev, int32_t width, int32_t height,
+int ht_resolve(ht_scene* scene, const int64_t* accum_dev, int32_t width, int32_t height,
                int64_t total_samples, float* rgb_linear, uint32_t* rgb_packed, void* stream);
 
 /* As ht_resolve, but the two pictures are DEVICE buffers on the scene's device and
  * the call only enqueues work on `stream` (no allocation, no host copy): for
  * callers that keep the frame on the GPU. */
-int ht_resolve_device(ht_scene* scene, const float* accum_dev, int32_t width, int32_t height,
+int ht_resolve_device(ht_scene* scene, const int64_t* accum_dev, int32_t width, int32_t height,
                       int64_t total_samples, float* rgb_linear_dev, uint32_t* rgb_packed_dev,
                       void* stream);
 
@@ -248,7 +259,8 @@ int ht_scene_get_info(const ht_scene* scene, ht_scene_info* out);
  *   "wait_threshold"    lanes of a wave that may wait for shading before
  *                       traversal yields (1..64)
  *   "max_blocks_per_cu" cap on resident workgroups per compute unit
- *   "default_batch"     samples per launch when ht_render_params.batch = 0 */
+ *   "default_batch"     samples per launch when ht_render_params.batch = 0
+ *   "chunk"             samples of one 8x8 tile that form one unit of the work queue */
 int ht_set_option(const char* name, int value);
 
 #ifdef __cplusplus

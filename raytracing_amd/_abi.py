@@ -91,6 +91,13 @@ class ht_stats(C.Structure):
         ("n_tex", C.c_int64 * 4),
         ("n_steps", C.c_int64),
         ("n_active", C.c_int64),
+        ("n_shade_rounds", C.c_int64),
+        ("n_regen_rounds", C.c_int64),
+        ("n_miss", C.c_int64),
+        ("cyc_trav", C.c_int64),
+        ("cyc_shade", C.c_int64),
+        ("cyc_regen", C.c_int64),
+        ("shader_clock_mhz", C.c_double),
     ]
 
     def as_dict(self):

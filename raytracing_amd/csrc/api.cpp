@@ -60,7 +60,8 @@ int fail(int code, const char* fmt, ...) {
 // tuning knobs (ht_set_option)
 std::atomic<int> g_wait_threshold{24};
 std::atomic<int> g_max_blocks_per_cu{2};
-std::atomic<int> g_default_batch{64};
+std::atomic<int> g_default_batch{256};
+std::atomic<int> g_chunk{8};
 
 // Makes `device` current for the lifetime of the object, then restores.
 struct DeviceGuard {
@@ -123,6 +124,7 @@ int ht_set_option(const char* name, int value) {
   if (!strcmp(name, "wait_threshold")) { g_wait_threshold = std::min(64, std::max(1, value)); return HT_OK; }
   if (!strcmp(name, "max_blocks_per_cu")) { g_max_blocks_per_cu = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "default_batch")) { g_default_batch = std::max(1, value); return HT_OK; }
+  if (!strcmp(name, "chunk")) { g_chunk = std::max(1, value); return HT_OK; }
   return fail(HT_E_INVALID, "unknown option '%s'", name);
 }
 
@@ -220,7 +222,7 @@ int ht_cancel(ht_scene* s) {
 }
 
 int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_params* p,
-                         float* accum_dev, void* stream_v, ht_stats* stats) {
+                         int64_t* accum_dev, void* stream_v, ht_stats* stats) {
   if (!s || !p || !accum_dev) return fail(HT_E_INVALID, "NULL argument");
   int rc = check_camera(cam);
   if (rc != HT_OK) return rc;
@@ -261,7 +263,8 @@ int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_para
   a.blob = prec == HT_PRECISION_FP32 ? s->d_blob32 : s->d_blob64;
   a.L = L;
   a.texels = s->d_texels;
-  a.accum = accum_dev;
+  a.accum = (long long*)accum_dev;
+  a.chunk = std::max(1, g_chunk.load());
   a.tile_counter = s->d_tile_counter;
   a.counters = counters ? s->d_counters : nullptr;
   a.W = p->width;
@@ -328,6 +331,13 @@ int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_para
         }
         stats->n_steps = (int64_t)h[CTR_STEPS];
         stats->n_active = (int64_t)h[CTR_ACTIVE];
+        stats->n_shade_rounds = (int64_t)h[CTR_SHADE_ROUNDS];
+        stats->n_regen_rounds = (int64_t)h[CTR_REGEN_ROUNDS];
+        stats->n_miss = (int64_t)h[CTR_MISS];
+        stats->cyc_trav = (int64_t)h[CTR_CYC_TRAV];
+        stats->cyc_shade = (int64_t)h[CTR_CYC_SHADE];
+        stats->cyc_regen = (int64_t)h[CTR_CYC_REGEN];
+        if (h[CTR_CLK_REAL]) stats->shader_clock_mhz = 100.0 * (double)h[CTR_CLK_SHADER] / (double)h[CTR_CLK_REAL];
       }
     }
     if (e != hipSuccess) {
@@ -346,18 +356,18 @@ int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_para
   return HT_OK;
 }
 
-int ht_resolve_device(ht_scene* s, const float* accum_dev, int32_t W, int32_t H, int64_t total_samples,
+int ht_resolve_device(ht_scene* s, const int64_t* accum_dev, int32_t W, int32_t H, int64_t total_samples,
                       float* rgb_linear_dev, uint32_t* rgb_packed_dev, void* stream_v) {
   if (!s || !accum_dev) return fail(HT_E_INVALID, "NULL argument");
   if (W < 1 || H < 1 || total_samples < 1) return fail(HT_E_INVALID, "bad resolve dimensions");
   DeviceGuard g(s->device);
   if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
-  HIP_TRY(launch_resolve(accum_dev, W, H, (float)(1.0 / (double)total_samples), rgb_linear_dev,
+  HIP_TRY(launch_resolve((const long long*)accum_dev, W, H, 1.0 / (double)total_samples, rgb_linear_dev,
                          rgb_packed_dev, (hipStream_t)stream_v));
   return HT_OK;
 }
 
-int ht_resolve(ht_scene* s, const float* accum_dev, int32_t W, int32_t H, int64_t total_samples,
+int ht_resolve(ht_scene* s, const int64_t* accum_dev, int32_t W, int32_t H, int64_t total_samples,
                float* rgb_linear, uint32_t* rgb_packed, void* stream_v) {
   if (!s || !accum_dev) return fail(HT_E_INVALID, "NULL argument");
   if (W < 1 || H < 1 || total_samples < 1) return fail(HT_E_INVALID, "bad resolve dimensions");
@@ -375,7 +385,7 @@ int ht_resolve(ht_scene* s, const float* accum_dev, int32_t W, int32_t H, int64_
       return fail(HT_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
     }
   }
-  hipError_t e = launch_resolve(accum_dev, W, H, (float)(1.0 / (double)total_samples), d_mean, d_packed, stream);
+  hipError_t e = launch_resolve((const long long*)accum_dev, W, H, 1.0 / (double)total_samples, d_mean, d_packed, stream);
   if (e == hipSuccess && rgb_linear)
     e = hipMemcpyAsync(rgb_linear, d_mean, n * 3 * sizeof(float), hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess && rgb_packed)
@@ -399,9 +409,9 @@ int ht_render(ht_scene* s, const ht_camera* cam, const ht_render_params* p, floa
   DeviceGuard g(s->device);
   if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
   const size_t n = (size_t)p->width * p->height;
-  float* d_accum = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_accum, n * 3 * sizeof(float)));
-  hipError_t e = hipMemsetAsync(d_accum, 0, n * 3 * sizeof(float), nullptr);
+  int64_t* d_accum = nullptr;
+  HIP_TRY(hipMalloc((void**)&d_accum, n * 3 * sizeof(int64_t)));
+  hipError_t e = hipMemsetAsync(d_accum, 0, n * 3 * sizeof(int64_t), nullptr);
   if (e != hipSuccess) {
     (void)hipFree(d_accum);
     return fail(HT_E_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));

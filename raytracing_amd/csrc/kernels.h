@@ -19,12 +19,13 @@ struct RenderArgs {
   const uint8_t* blob;     // scene image in global memory (copied to LDS per workgroup)
   SceneLayout L;
   const uint32_t* texels;  // image texels, 0x00RRGGBB
-  float* accum;            // [H*W*3] radiance sums, row 0 = bottom
-  uint32_t* tile_counter;  // zeroed before every launch
+  long long* accum;        // [H*W*3] radiance sums, signed 32.32 fixed point, row 0 = bottom
+  uint32_t* tile_counter;  // work-unit queue head, zeroed before every launch
   unsigned long long* counters;  // NUM_COUNTERS words, or nullptr
   int32_t W, H;
   int32_t sample_first;    // global index of the first sample of this launch
   int32_t sample_count;    // samples per pixel in this launch
+  int32_t chunk;           // samples per work unit
   int32_t max_depth;
   int32_t jitter;
   uint32_t seed_lo, seed_hi;
@@ -44,7 +45,9 @@ enum {
   CTR_RAYS = 0, CTR_BOX, CTR_SPHERE, CTR_RECT, CTR_TRI,
   CTR_SHADE0, CTR_SHADE1, CTR_SHADE2, CTR_SHADE3,
   CTR_TEX0, CTR_TEX1, CTR_TEX2, CTR_TEX3,
-  CTR_STEPS, CTR_ACTIVE,
+  CTR_STEPS, CTR_ACTIVE, CTR_SHADE_ROUNDS, CTR_REGEN_ROUNDS, CTR_MISS,
+  CTR_CYC_TRAV, CTR_CYC_SHADE, CTR_CYC_REGEN,  // wave cycles per phase (lane 0 of every wave)
+  CTR_CLK_SHADER, CTR_CLK_REAL,  // s_memtime / s_memrealtime ticks of workgroup 0
   NUM_COUNTERS
 };
 
@@ -63,7 +66,7 @@ hipError_t launch_render(int precision, bool counters, const RenderArgs& a, cons
 hipError_t launch_first_hit(int precision, const FirstHitArgs& a, const void* cam,
                             uint32_t lds_bytes, hipStream_t stream);
 // mean + Vec3.toRGB + row flip (Vec3.scala:82-84, main.scala:93)
-hipError_t launch_resolve(const float* accum, int32_t W, int32_t H, float inv_samples,
+hipError_t launch_resolve(const long long* accum, int32_t W, int32_t H, double inv_samples,
                           float* rgb_mean, uint32_t* rgb_packed, hipStream_t stream);
 
 }  // namespace ht

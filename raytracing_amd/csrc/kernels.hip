@@ -563,12 +563,46 @@ __device__ __forceinline__ V3<R> unit_vector_from(R u0, R u1) {
   return mk<R>(r * c, r * s, z);
 }
 
+// Radiance sums are kept in signed 32.32 fixed point: integer adds commute, so a
+// pixel's sum does not depend on the order in which its paths finish, on how
+// the frame is cut into launches or on how many GPUs share it.
+template <typename R>
+__device__ __forceinline__ long long to_fixed(R x) {
+  const R f = M<R>::floor(x);
+  const int hi = (int)f;                                        // saturates; NaN -> 0
+  const unsigned lo = (unsigned)((x - f) * (R)4294967296.0);    // [0, 2^32)
+  return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)lo);
+}
+// Where a finished path's contribution goes: the wave's LDS tile while the
+// path's work unit is still the wave's current one, else (a straggler of an
+// older unit) straight to the frame buffer.
+struct Sink {
+  unsigned long long* lds;     // this pixel's three LDS accumulators
+  unsigned long long* global;  // this pixel's three frame accumulators
+  bool current;
+};
+template <typename R>
+__device__ __forceinline__ void deposit(const Sink& k, V3<R> c) {
+  const unsigned long long r = (unsigned long long)to_fixed<R>(c.x);
+  const unsigned long long g = (unsigned long long)to_fixed<R>(c.y);
+  const unsigned long long b = (unsigned long long)to_fixed<R>(c.z);
+  if (k.current) {
+    atomicAdd(k.lds + 0, r);
+    atomicAdd(k.lds + 1, g);
+    atomicAdd(k.lds + 2, b);
+  } else {
+    atomicAdd(k.global + 0, r);
+    atomicAdd(k.global + 1, g);
+    atomicAdd(k.global + 2, b);
+  }
+}
+
 // material.scatter + material.emit for the closest hit (Material.scala:9-55,
 // Camera.scala:29-33).  Returns true when the path continues with `ray`
 // replaced by the scattered ray and T multiplied by the attenuation.
 template <typename R, bool CNT>
 __device__ __forceinline__ bool shade_hit(const Scene& sc, const RenderArgs& A, Ray<R>& ray,
-                                          const Trav<R>& tv, V3<R>& T, V3<R>& sum, uint32_t pixel,
+                                          const Trav<R>& tv, V3<R>& T, const Sink& sink, uint32_t pixel,
                                           uint32_t sample, uint32_t bounce, Cnt& cnt) {
   HitGeom<R> h = hit_geometry<R>(sc, ray, tv.best_t, tv.best_ref);
   typename M<R>::R4 m = load_r4<R>(sc, sc.L.mat, h.meta >> META_MAT_SHIFT);
@@ -580,7 +614,7 @@ __device__ __forceinline__ bool shade_hit(const Scene& sc, const RenderArgs& A, 
   const V3<R> n = front ? h.n_out : -h.n_out;             // Hit.normal (not normalised)
   V3<R> col = texture_eval<R, CNT>(sc, A.texels, tex, ray, h, cnt);
   if (mkind == 3u) {  // Emission: never scatters, emits on both faces
-    sum = sum + T * (param * col);
+    deposit<R>(sink, T * (param * col));
     return false;
   }
   uint32_t rnd[4];
@@ -663,6 +697,19 @@ __device__ __forceinline__ void copy_scene_to_lds(uint8_t* lds, const uint8_t* b
 
 enum : uint32_t { ST_TRAV = 0, ST_WAIT = 1, ST_DEAD = 2, ST_DONE = 3 };
 
+// LDS of a render workgroup: [scene image][traversal stacks][per-wave tile sums]
+__host__ __device__ inline uint32_t stack_bytes(uint32_t threads, uint32_t depth) {
+  return threads * 4u * (depth + 1u);
+}
+constexpr uint32_t TILE_PIXELS = TILE_W * TILE_H;       // 64 = one wave
+constexpr uint32_t TILE_ACC_BYTES = TILE_PIXELS * 3u * 8u;
+
+// The path-tracing kernel.  Work is a global queue of units; unit u is CHUNK
+// consecutive samples of one 8x8 tile (chunk-major order, so the units of an
+// expensive tile are spread over the whole launch).  A wave streams units: its
+// dead lanes claim the next (pixel, sample) items of the current unit, and when
+// the unit runs out the wave moves on to the next one at once while the
+// stragglers of the old unit are still in flight.
 template <typename R, bool CNT>
 __global__ void __launch_bounds__(M<R>::BT) render_kernel(RenderArgs A, CamDev<R> cam) {
   extern __shared__ __align__(16) uint8_t lds[];
@@ -673,98 +720,175 @@ __global__ void __launch_bounds__(M<R>::BT) render_kernel(RenderArgs A, CamDev<R
   sc.L = A.L;
   uint32_t* stack_lane = (uint32_t*)(lds + A.L.total_bytes) + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63u;
+  unsigned long long* tile_acc = (unsigned long long*)(lds + A.L.total_bytes + stack_bytes(BT, A.L.depth) +
+                                                       (threadIdx.x >> 6) * TILE_ACC_BYTES);
+  unsigned long long* frame = (unsigned long long*)A.accum;
   const uint32_t tiles_x = (uint32_t)(A.W + TILE_W - 1) / TILE_W;
   const uint32_t tiles_y = (uint32_t)(A.H + TILE_H - 1) / TILE_H;
   const uint32_t n_tiles = tiles_x * tiles_y;
+  const uint32_t chunk = (uint32_t)A.chunk;
+  const uint32_t n_chunks = ((uint32_t)A.sample_count + chunk - 1u) / chunk;
+  const uint32_t n_units = n_tiles * n_chunks;
   const R t_min = (R)0.001;  // Camera.scala:28
   const V3<R> bg = ld3<R>(cam.background);
   Cnt cnt;
+  uint64_t clk0 = 0, real0 = 0;
   if (CNT) {
 #pragma unroll
     for (int k = 0; k < NUM_COUNTERS; ++k) cnt.v[k] = 0;
+    clk0 = __builtin_amdgcn_s_memtime();
+    real0 = __builtin_amdgcn_s_memrealtime();
   }
+  tile_acc[lane * 3u + 0u] = 0ull;
+  tile_acc[lane * 3u + 1u] = 0ull;
+  tile_acc[lane * 3u + 2u] = 0ull;
+
+  // wave-uniform state of the current unit
+  uint32_t epoch = 0;          // number of units this wave has opened
+  uint32_t next_item = 0, pool_size = 0;
+  uint32_t tile_x0 = 0, tile_y0 = 0, sample_base = 0;
+  bool queue_empty = false;
+
+  // per-lane path state
+  Ray<R> ray;
+  Trav<R> tv;
+  V3<R> T = mk<R>((R)1, (R)1, (R)1);
+  uint32_t state = ST_DEAD;
+  uint32_t my_epoch = 0, pix = 0, pixel = 0, sample = 0, bounce = 0;
+  ray.o = ray.d = ray.inv = mk<R>((R)0, (R)0, (R)0);
+  ray.a = ray.inv_a = ray.oo = (R)0;
+  trav_begin<R>(tv);
+
+  // adds the wave's tile sums to the frame and clears them
+  auto flush_tile = [&]() {
+    const uint32_t px = tile_x0 + (lane & 7u), py = tile_y0 + (lane >> 3);
+    if (px < (uint32_t)A.W && py < (uint32_t)A.H) {
+      unsigned long long* out = frame + ((size_t)py * (uint32_t)A.W + px) * 3u;
+#pragma unroll
+      for (uint32_t c = 0; c < 3u; ++c) {
+        const unsigned long long v = tile_acc[lane * 3u + c];
+        if (v != 0ull) atomicAdd(out + c, v);
+        tile_acc[lane * 3u + c] = 0ull;
+      }
+    }
+  };
 
   for (;;) {
-    uint32_t tile = 0;
-    if (lane == 0) tile = atomicAdd(A.tile_counter, 1u);
-    tile = __shfl(tile, 0);
-    if (tile >= n_tiles) break;
-    const uint32_t px = (tile % tiles_x) * TILE_W + (lane & 7u);
-    const uint32_t py = (tile / tiles_x) * TILE_H + (lane >> 3);
-    const bool valid = px < (uint32_t)A.W && py < (uint32_t)A.H;
-    const uint32_t pixel = py * (uint32_t)A.W + px;
-
-    Ray<R> ray;
-    Trav<R> tv;
-    V3<R> T = mk<R>((R)1, (R)1, (R)1);
-    V3<R> sum = mk<R>((R)0, (R)0, (R)0);
-    uint32_t state = valid ? ST_DEAD : ST_DONE;
-    uint32_t s_next = 0;  // next sample of this pixel to start
-    uint32_t sample = 0, bounce = 0;
-    ray.o = ray.d = ray.inv = mk<R>((R)0, (R)0, (R)0);
-    ray.a = ray.inv_a = ray.oo = (R)0;
-    trav_begin<R>(tv);
-
+    uint64_t ts0 = 0;
+    if (CNT) ts0 = __builtin_amdgcn_s_memtime();
+    // ---- shade the lanes whose ray is finished --------------------------------
+    if (CNT) {
+      const uint64_t w = __ballot(state == ST_WAIT);
+      if (lane == 0 && w != 0ull) cnt.v[CTR_SHADE_ROUNDS]++;
+    }
+    if (state == ST_WAIT) {
+      Sink sink;
+      sink.lds = tile_acc + pix * 3u;
+      sink.global = frame + (size_t)pixel * 3u;
+      sink.current = my_epoch == epoch;
+      bool cont;
+      if (tv.best_ref == REF_EMPTY) {
+        deposit<R>(sink, T * bg);  // case None => background (Camera.scala:34)
+        cont = false;
+        if (CNT) cnt.v[CTR_MISS]++;
+      } else {
+        cont = shade_hit<R, CNT>(sc, A, ray, tv, T, sink, pixel, sample, bounce, cnt);
+        // depth exhausted: the next ray_color call returns 0 (Camera.scala:27)
+        if (cont && bounce >= (uint32_t)A.max_depth) cont = false;
+      }
+      if (cont) {
+        bounce++;
+        trav_begin<R>(tv);
+        state = ST_TRAV;
+        if (CNT) cnt.v[CTR_RAYS]++;
+      } else {
+        state = ST_DEAD;
+      }
+    }
+    uint64_t ts1 = 0;
+    if (CNT) ts1 = __builtin_amdgcn_s_memtime();
+    // ---- dead lanes claim the next items and start their camera paths ---------------
     for (;;) {
-      // ---- shade the lanes whose ray is finished --------------------------------
-      if (state == ST_WAIT) {
-        bool cont;
-        if (tv.best_ref == REF_EMPTY) {
-          sum = sum + T * bg;  // case None => background (Camera.scala:34)
-          cont = false;
-        } else {
-          cont = shade_hit<R, CNT>(sc, A, ray, tv, T, sum, pixel, sample, bounce, cnt);
-          // depth exhausted: the next ray_color call returns 0 (Camera.scala:27)
-          if (cont && bounce >= (uint32_t)A.max_depth) cont = false;
+      const uint64_t dead = __ballot(state == ST_DEAD);
+      if (dead == 0ull) break;
+      if (next_item >= pool_size) {  // wave-uniform: the current unit is used up
+        if (queue_empty) {
+          if (state == ST_DEAD) state = ST_DONE;
+          break;
         }
-        if (cont) {
-          bounce++;
-          trav_begin<R>(tv);
-          state = ST_TRAV;
-          if (CNT) cnt.v[CTR_RAYS]++;
-        } else {
-          state = ST_DEAD;
+        if (epoch != 0u) flush_tile();
+        uint32_t unit = 0;
+        if (lane == 0) unit = atomicAdd(A.tile_counter, 1u);
+        unit = __shfl(unit, 0);
+        if (unit >= n_units) {
+          queue_empty = true;
+          epoch++;  // whatever is still in flight deposits to the frame directly
+          continue;
         }
+        const uint32_t tile = unit % n_tiles, ck = unit / n_tiles;
+        tile_x0 = (tile % tiles_x) * TILE_W;
+        tile_y0 = (tile / tiles_x) * TILE_H;
+        sample_base = (uint32_t)A.sample_first + ck * chunk;
+        pool_size = TILE_PIXELS * min(chunk, (uint32_t)A.sample_count - ck * chunk);
+        next_item = 0;
+        epoch++;
+        continue;
       }
-      // ---- start the pixel's next camera path on dead lanes -----------------------
+      if (CNT && lane == 0) cnt.v[CTR_REGEN_ROUNDS]++;
       if (state == ST_DEAD) {
-        if (s_next < (uint32_t)A.sample_count) {
-          sample = (uint32_t)A.sample_first + s_next;
-          s_next++;
-          camera_ray<R>(A, cam, ray, px, py, pixel, sample);
-          T = mk<R>((R)1, (R)1, (R)1);
-          bounce = 1;
-          trav_begin<R>(tv);
-          state = ST_TRAV;
-          if (CNT) cnt.v[CTR_RAYS]++;
-        } else {
-          state = ST_DONE;
+        const uint32_t item = next_item + (uint32_t)__popcll(dead & ((1ull << lane) - 1ull));
+        if (item < pool_size) {
+          pix = item & (TILE_PIXELS - 1u);
+          const uint32_t px = tile_x0 + (pix & 7u), py = tile_y0 + (pix >> 3);
+          if (px < (uint32_t)A.W && py < (uint32_t)A.H) {  // else: claim again next round
+            pixel = py * (uint32_t)A.W + px;
+            sample = sample_base + (item >> 6);
+            my_epoch = epoch;
+            camera_ray<R>(A, cam, ray, px, py, pixel, sample);
+            T = mk<R>((R)1, (R)1, (R)1);
+            bounce = 1;
+            trav_begin<R>(tv);
+            state = ST_TRAV;
+            if (CNT) cnt.v[CTR_RAYS]++;
+          }
         }
       }
-      if (__ballot(state == ST_TRAV) == 0ull) break;  // every lane is DONE
-      // ---- traversal, until enough lanes wait for shading --------------------------
-      for (;;) {
-        if (state == ST_TRAV) {
-          trav_step<R, CNT>(sc, ray, tv, stack_lane, t_min, cnt);
-          if (tv.cur == REF_EMPTY) state = ST_WAIT;
-          if (CNT) cnt.v[CTR_ACTIVE]++;
-        }
-        if (CNT) cnt.v[CTR_STEPS]++;
-        const uint64_t trav = __ballot(state == ST_TRAV);
-        const uint64_t wait = __ballot(state == ST_WAIT);
-        if (trav == 0ull || __popcll(wait) >= A.wait_threshold) break;
+      next_item = min(pool_size, next_item + (uint32_t)__popcll(dead));
+    }
+    uint64_t ts2 = 0;
+    if (CNT) {
+      ts2 = __builtin_amdgcn_s_memtime();
+      if (lane == 0) {
+        cnt.v[CTR_CYC_SHADE] += (uint32_t)(ts1 - ts0);
+        cnt.v[CTR_CYC_REGEN] += (uint32_t)(ts2 - ts1);
       }
     }
-    if (valid) {
-      float* out = A.accum + (size_t)pixel * 3u;
-      out[0] += (float)sum.x;
-      out[1] += (float)sum.y;
-      out[2] += (float)sum.z;
+    if (__ballot(state == ST_TRAV) == 0ull) break;  // the queue is empty and every path ended
+    // ---- traversal, until enough lanes wait for shading --------------------------
+    for (;;) {
+      if (state == ST_TRAV) {
+        trav_step<R, CNT>(sc, ray, tv, stack_lane, t_min, cnt);
+        if (tv.cur == REF_EMPTY) state = ST_WAIT;
+        if (CNT) cnt.v[CTR_ACTIVE]++;
+      }
+      if (CNT) cnt.v[CTR_STEPS]++;
+      const uint64_t trav = __ballot(state == ST_TRAV);
+      const uint64_t wait = __ballot(state == ST_WAIT);
+      if (trav == 0ull || __popcll(wait) >= A.wait_threshold) break;
     }
+    if (CNT && lane == 0) cnt.v[CTR_CYC_TRAV] += (uint32_t)(__builtin_amdgcn_s_memtime() - ts2);
   }
+  // the last unit's sums (epoch was bumped when the queue ran dry, so every later
+  // deposit went to the frame; what is left in LDS belongs to the last real unit)
+  flush_tile();
+
   if (CNT && A.counters) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      A.counters[CTR_CLK_SHADER] = __builtin_amdgcn_s_memtime() - clk0;
+      A.counters[CTR_CLK_REAL] = __builtin_amdgcn_s_memrealtime() - real0;
+    }
 #pragma unroll
-    for (int k = 0; k < NUM_COUNTERS; ++k) {
+    for (int k = 0; k < CTR_CLK_SHADER; ++k) {
       // wave reduction, then one atomic per wave
       uint32_t v = cnt.v[k];
       unsigned long long tot = v;
@@ -827,10 +951,11 @@ __global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, Cam
   }
 }
 
-// mean radiance, Vec3.toRGB (Vec3.scala:82-84: 255 * clamp(sqrt(x), 0, 0.999),
-// truncated; NaN -> 0) and the row flip of img.setRGB(i, H-j-1, ..) (main.scala:93)
-__global__ void resolve_kernel(const float* __restrict__ accum, int32_t W, int32_t H,
-                               float inv_samples, float* __restrict__ rgb_mean,
+// mean radiance from the 32.32 fixed-point sums, Vec3.toRGB (Vec3.scala:82-84:
+// 255 * clamp(sqrt(x), 0, 0.999), truncated; NaN -> 0) and the row flip of
+// img.setRGB(i, H-j-1, ..) (main.scala:93)
+__global__ void resolve_kernel(const long long* __restrict__ accum, int32_t W, int32_t H,
+                               double inv_samples, float* __restrict__ rgb_mean,
                                uint32_t* __restrict__ rgb_packed) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (uint32_t)(W * H)) return;
@@ -838,9 +963,9 @@ __global__ void resolve_kernel(const float* __restrict__ accum, int32_t W, int32
   uint32_t code = 0;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    float m = accum[(size_t)p * 3u + c] * inv_samples;
-    if (rgb_mean) rgb_mean[(size_t)p * 3u + c] = m;
-    double g = ::sqrt((double)m);
+    const double m = (double)accum[(size_t)p * 3u + c] * (1.0 / 4294967296.0) * inv_samples;
+    if (rgb_mean) rgb_mean[(size_t)p * 3u + c] = (float)m;
+    double g = ::sqrt(m);
     g = ::fmin(::fmax(g, 0.0), 0.999);  // fmax(NaN, 0) = 0, the value NaN.toInt gives
     code = (code << 8) | (uint32_t)(int)(255.0 * g);
   }
@@ -852,7 +977,7 @@ __global__ void resolve_kernel(const float* __restrict__ accum, int32_t W, int32
 // ---------------------------------------------------------------------------
 uint32_t lds_bytes_needed(const SceneLayout& L, int precision) {
   const uint32_t bt = precision == 0 ? M<float>::BT : M<double>::BT;
-  return L.total_bytes + bt * 4u * (L.depth + 1u);
+  return L.total_bytes + stack_bytes(bt, L.depth) + (bt / 64u) * TILE_ACC_BYTES;
 }
 
 template <typename K>
@@ -925,7 +1050,7 @@ hipError_t launch_first_hit(int precision, const FirstHitArgs& a, const void* ca
   return hipGetLastError();
 }
 
-hipError_t launch_resolve(const float* accum, int32_t W, int32_t H, float inv_samples, float* rgb_mean,
+hipError_t launch_resolve(const long long* accum, int32_t W, int32_t H, double inv_samples, float* rgb_mean,
                           uint32_t* rgb_packed, hipStream_t stream) {
   const uint32_t n = (uint32_t)(W * H);
   hipLaunchKernelGGL(resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, accum, W, H,

@@ -22,13 +22,13 @@ def hip():
 
 
 class DeviceBuffer:
-    """A zero-initialised float32 device array."""
+    """A zero-initialised int64 device array (radiance sums, 32.32 fixed point)."""
 
-    def __init__(self, n_floats: int):
-        self.n = n_floats
+    def __init__(self, n: int):
+        self.n = n
         self.ptr = C.c_void_p()
-        assert hip().hipMalloc(C.byref(self.ptr), n_floats * 4) == 0
-        assert hip().hipMemset(self.ptr, 0, n_floats * 4) == 0
+        assert hip().hipMalloc(C.byref(self.ptr), n * 8) == 0
+        assert hip().hipMemset(self.ptr, 0, n * 8) == 0
         assert hip().hipDeviceSynchronize() == 0
 
     @property
@@ -36,9 +36,9 @@ class DeviceBuffer:
         return self.ptr.value
 
     def to_host(self) -> np.ndarray:
-        out = np.empty(self.n, dtype=np.float32)
+        out = np.empty(self.n, dtype=np.int64)
         assert hip().hipDeviceSynchronize() == 0
-        assert hip().hipMemcpy(out.ctypes.data_as(C.c_void_p), self.ptr, self.n * 4, 2) == 0  # D2H
+        assert hip().hipMemcpy(out.ctypes.data_as(C.c_void_p), self.ptr, self.n * 8, 2) == 0  # D2H
         return out
 
     def free(self):

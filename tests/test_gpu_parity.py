@@ -3,8 +3,7 @@ need a real MI355X: run with -m gpu.
 
 Tolerances
   * fp64 device path: same arithmetic as the oracle up to fused multiply-adds and
-    libm differences -> 1e-9 relative on t, 1e-8 on normals (as vectors), 2e-6 absolute on radiance (the
-    accumulation buffer is fp32).
+    libm differences -> 1e-9 relative on t, 1e-8 on normals (as vectors), 3e-6 on radiance.
   * fp32 device path (the production path): primitive ids exact wherever the oracle's
     own answer is stable under a ~1 ulp perturbation of the ray; t and normal within
     1e-5 relative, widened per pixel by 8x the oracle's sensitivity to that same
@@ -187,32 +186,36 @@ def test_full_size_properties(dev, flat_scene, name, W, H):
 
     whole_buf = sums(0, 6)
     whole = whole_buf.to_host()
-    # determinism: the same call twice is bit-identical
+    # radiance sums are integers (32.32 fixed point), so all of these are EXACT:
+    # the same call twice
     assert np.array_equal(whole, sums(0, 6).to_host())
-    # sample ranges are additive (what spp sharding over GPUs relies on); only the fp32
-    # summation order differs
-    parts = sums(0, 2).to_host() + sums(2, 4).to_host()
-    np.testing.assert_allclose(whole, parts, rtol=2e-6, atol=1e-6)
-    # accumulating two calls into ONE buffer is the same sum
+    # sample ranges are additive (what spp sharding over GPUs relies on)
+    assert np.array_equal(whole, sums(0, 2).to_host() + sums(2, 4).to_host())
+    # accumulating two calls into ONE buffer
     acc = sums(0, 2)
     p = dev.make_params(W, H, 4, sample_offset=2, seed=9, device=0)
     s.render_accumulate(cam, p, acc.address, 0)
-    np.testing.assert_allclose(whole, acc.to_host(), rtol=2e-6, atol=1e-6)
-    # the launch batch size does not change the set of paths
-    np.testing.assert_allclose(whole, sums(0, 6, batch=1).to_host(), rtol=2e-6, atol=1e-6)
+    assert np.array_equal(whole, acc.to_host())
+    # the launch batch size and the work-unit size do not change anything
+    assert np.array_equal(whole, sums(0, 6, batch=1).to_host())
+    dev.set_option("chunk", 3)
+    try:
+        assert np.array_equal(whole, sums(0, 6).to_host())
+    finally:
+        dev.set_option("chunk", 8)
     # radiance is bounded by the brightest source times the largest albedo chain (<= 1)
+    one = 2.0 ** 32
     bright = 15.0 if name == "cornell" else 1.0
-    assert float(whole.max()) <= 6 * bright * (1 + 1e-5) and float(whole.min()) >= 0.0
-    assert np.isfinite(whole).all()
+    assert int(whole.max()) <= 6 * bright * one * (1 + 1e-5) and int(whole.min()) >= 0
     # resolve: codes <= 254 per channel (Vec3.scala:82-84) and the picture is the row flip
     out = s.resolve(whole_buf.address, W, H, 6, 0)
     codes = out["packed"]
     assert int(((codes >> 16) & 255).max()) <= 254 and int((codes & 255).max()) <= 254
-    mean = whole.reshape(H, W, 3) / 6
+    mean = whole.reshape(H, W, 3).astype(np.float64) / one / 6
     np.testing.assert_allclose(out["rgb"], mean, rtol=1e-6, atol=1e-7)
-    top_row = np.floor(255 * np.clip(np.sqrt(mean[H - 1].astype(np.float64)), 0, 0.999)).astype(np.uint32)
+    top_row = np.floor(255 * np.clip(np.sqrt(mean[H - 1]), 0, 0.999)).astype(np.uint32)
     got = np.stack([(codes[0] >> 16) & 255, (codes[0] >> 8) & 255, codes[0] & 255], -1)
-    assert (np.abs(got.astype(int) - top_row.astype(int)) <= 1).all()
+    assert np.array_equal(got, top_row)
 
 
 def test_jitter_off_render_equals_first_hit_shading(dev, oracle_mod, flat_scene):

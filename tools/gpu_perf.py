@@ -12,9 +12,9 @@ ap.add_argument("scenes", nargs="*", default=["dragon", "random", "cornell"])
 ap.add_argument("--w", type=int, default=1920); ap.add_argument("--h", type=int, default=1080)
 ap.add_argument("--spp", type=int, default=64); ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--wait", type=int, nargs="*", default=[24]); ap.add_argument("--bpc", type=int, default=2)
-ap.add_argument("--counters", type=int, default=1); ap.add_argument("--prec", type=int, default=0)
+ap.add_argument("--counters", type=int, default=1); ap.add_argument("--chunk", type=int, default=8); ap.add_argument("--prec", type=int, default=0)
 a = ap.parse_args()
-ht.set_option("max_blocks_per_cu", a.bpc)
+ht.set_option("max_blocks_per_cu", a.bpc); ht.set_option("chunk", a.chunk)
 for name in a.scenes:
     cam, world = load_scene(f"{SC}/{name}.json")
     flat = flatten(world)
@@ -25,10 +25,10 @@ for name in a.scenes:
             ht.set_option("wait_threshold", wt)
             r = s.render(cam, W, H, a.spp, precision=a.prec, batch=a.batch, seed=1)
             st = r["stats"]
-            line = f"{name:8s} {W}x{H}x{a.spp} wait={wt} kernel_s={st['seconds_kernel']:.4f} Msamples/s={st['samples']/st['seconds_kernel']/1e6:.1f} mean={r['rgb'].mean():.5f}"
+            line = f"{name:8s} {W}x{H}x{a.spp} chunk={a.chunk} batch={a.batch} wait={wt} kernel_s={st['seconds_kernel']:.4f} Msamples/s={st['samples']/st['seconds_kernel']/1e6:.1f} mean={r['rgb'].mean():.5f}"
             if a.counters:
-                r2 = s.render(cam, W, H, min(a.spp, 16), precision=a.prec, batch=a.batch, seed=1, collect_counters=1)
+                r2 = s.render(cam, W, H, a.spp, precision=a.prec, batch=a.batch, seed=1, collect_counters=1)
                 c = r2["stats"]; ns = c["samples"]
                 flops = 40 * ns + 18 * c["n_box"] + 25 * c["n_sphere"] + 12 * c["n_rect"] + 38 * c["n_tri"] + 40 * c["n_shade"][0] + 50 * c["n_shade"][1] + 65 * c["n_shade"][2] + 700 * c["n_tex"][2] + 8 * c["n_tex"][3]
-                line += f" rays/s={c['n_rays']/ns:.2f} box/ray={c['n_box']/c['n_rays']:.1f} prim/ray={(c['n_sphere']+c['n_rect']+c['n_tri'])/c['n_rays']:.2f} flop/sample={flops/ns:.0f} util={c['n_active']/max(1,c['n_steps']):.3f} TFLOPs={flops/ns*st['samples']/st['seconds_kernel']/1e12:.2f}"
+                line += f" rays/s={c['n_rays']/ns:.2f} box/ray={c['n_box']/c['n_rays']:.1f} prim/ray={(c['n_sphere']+c['n_rect']+c['n_tri'])/c['n_rays']:.2f} flop/sample={flops/ns:.0f} util={c['n_active']/max(1,c['n_steps']):.3f} iters/sample={c['n_steps']/64/ns:.3f} shade_rounds/sample={c['n_shade_rounds']/ns:.3f} lanes/shade_round={(sum(c['n_shade'])+c['n_miss'])/max(1,c['n_shade_rounds']):.1f} regen_rounds/sample={c['n_regen_rounds']/ns:.3f} lanes/regen={ns/max(1,c['n_regen_rounds']):.1f} cyc/sample trav={c['cyc_trav']/ns:.1f} shade={c['cyc_shade']/ns:.1f} regen={c['cyc_regen']/ns:.1f} clk={c['shader_clock_mhz']:.0f}MHz ctr_kernel_s={c['seconds_kernel']:.4f} TFLOPs={flops/ns*st['samples']/st['seconds_kernel']/1e12:.2f}"
             print(line, flush=True)
