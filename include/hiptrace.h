@@ -167,6 +167,10 @@ typedef struct ht_stats {
   int64_t n_regen_rounds; /* wave-level camera-path start rounds                     */
   int64_t n_miss;         /* paths that left the scene (background)                  */
   int64_t cyc_trav, cyc_shade, cyc_regen; /* wave cycles spent per phase, summed over waves */
+  int32_t block_threads;  /* launch shape of the path-tracing kernel: threads per workgroup, */
+  int32_t blocks_per_cu;  /*   resident workgroups per compute unit,                        */
+  int32_t lds_bytes;      /*   LDS bytes per workgroup (scene image + stacks + tile sums)   */
+  int32_t n_cu;           /*   compute units of the device                                  */
   double shader_clock_mhz; /* in-kernel clock: s_memtime ticks per 100 MHz s_memrealtime tick */
 } ht_stats;
 
@@ -259,6 +263,10 @@ int ht_scene_get_info(const ht_scene* scene, ht_scene_info* out);
  *   "wait_threshold"    lanes of a wave that may wait for shading before
  *                       traversal yields (1..64)
  *   "max_blocks_per_cu" cap on resident workgroups per compute unit
+ *   "block_threads"     force the workgroup size (multiple of 128; 0 = choose for occupancy)
+ *   "node_den"          node steps continue while inner-node lanes * node_den >= travelling lanes
+ *   "wait_ratio_num" / "wait_ratio_den"  traversal also yields to shading when
+ *                       waiting lanes / travelling lanes >= num / den
  *   "default_batch"     samples per launch when ht_render_params.batch = 0
  *   "chunk"             samples of one 8x8 tile that form one unit of the work queue */
 int ht_set_option(const char* name, int value);

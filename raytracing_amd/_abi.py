@@ -97,6 +97,10 @@ class ht_stats(C.Structure):
         ("cyc_trav", C.c_int64),
         ("cyc_shade", C.c_int64),
         ("cyc_regen", C.c_int64),
+        ("block_threads", C.c_int32),
+        ("blocks_per_cu", C.c_int32),
+        ("lds_bytes", C.c_int32),
+        ("n_cu", C.c_int32),
         ("shader_clock_mhz", C.c_double),
     ]
 

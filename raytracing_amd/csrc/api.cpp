@@ -31,6 +31,7 @@ struct ht_scene {
   uint32_t* d_tile_counter = nullptr;
   unsigned long long* d_counters = nullptr;
   std::atomic<int> cancel{0};
+  uint32_t feat = 0;  // KFEAT_* texture kinds present in the scene
 };
 
 namespace {
@@ -58,8 +59,10 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 // tuning knobs (ht_set_option)
-std::atomic<int> g_wait_threshold{24};
-std::atomic<int> g_max_blocks_per_cu{2};
+std::atomic<int> g_wait_threshold{40};
+std::atomic<int> g_max_blocks_per_cu{8};
+std::atomic<int> g_block_threads{0};  // 0: choose
+std::atomic<int> g_node_den{2}, g_wait_num{1000}, g_wait_den{1};
 std::atomic<int> g_default_batch{256};
 std::atomic<int> g_chunk{8};
 
@@ -125,6 +128,10 @@ int ht_set_option(const char* name, int value) {
   if (!strcmp(name, "max_blocks_per_cu")) { g_max_blocks_per_cu = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "default_batch")) { g_default_batch = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "chunk")) { g_chunk = std::max(1, value); return HT_OK; }
+  if (!strcmp(name, "block_threads")) { g_block_threads = value; return HT_OK; }
+  if (!strcmp(name, "node_den")) { g_node_den = std::max(1, value); return HT_OK; }
+  if (!strcmp(name, "wait_ratio_num")) { g_wait_num = std::max(1, value); return HT_OK; }
+  if (!strcmp(name, "wait_ratio_den")) { g_wait_den = std::max(1, value); return HT_OK; }
   return fail(HT_E_INVALID, "unknown option '%s'", name);
 }
 
@@ -173,8 +180,12 @@ int ht_scene_create(const ht_scene_desc* desc, int device, ht_scene** out) {
   if (e != hipSuccess) { delete s; return fail(HT_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); }
   s->n_cu = prop.multiProcessorCount;
   const size_t lds_cap = prop.sharedMemPerBlock;  // 160 KiB on gfx950
-  if (lds_bytes_needed(s->hs.layout32, HT_PRECISION_FP32) > lds_cap) {
-    uint32_t need = lds_bytes_needed(s->hs.layout32, HT_PRECISION_FP32);
+  for (int t : s->hs.tex_type) {
+    if (t == HT_TEX_PERLIN) s->feat |= KFEAT_PERLIN;
+    if (t == HT_TEX_IMAGE) s->feat |= KFEAT_IMAGE;
+  }
+  if (lds_bytes_needed(s->hs.layout32, 256) > lds_cap) {
+    uint32_t need = lds_bytes_needed(s->hs.layout32, 256);
     delete s;
     return fail(HT_E_TOO_LARGE,
                 "scene image + traversal stacks need %u bytes of LDS, the device offers %zu per "
@@ -209,8 +220,8 @@ int ht_scene_get_info(const ht_scene* s, ht_scene_info* out) {
   out->bvh_depth = s->hs.depth;
   out->n_materials = (int32_t)s->hs.mat_type.size();
   out->n_textures = (int32_t)s->hs.tex_type.size();
-  out->lds_bytes_fp32 = (int32_t)lds_bytes_needed(s->hs.layout32, HT_PRECISION_FP32);
-  out->lds_bytes_fp64 = (int32_t)lds_bytes_needed(s->hs.layout64, HT_PRECISION_FP64);
+  out->lds_bytes_fp32 = (int32_t)s->hs.layout32.total_bytes;
+  out->lds_bytes_fp64 = (int32_t)s->hs.layout64.total_bytes;
   out->device = s->device;
   return HT_OK;
 }
@@ -243,11 +254,21 @@ int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_para
   const int prec = p->precision;
   const bool counters = p->collect_counters != 0;
   const SceneLayout& L = prec == HT_PRECISION_FP32 ? s->hs.layout32 : s->hs.layout64;
-  const uint32_t lds = lds_bytes_needed(L, prec);
-  int bpc = render_blocks_per_cu(prec, counters, lds);
+  // workgroup size and count: the combination that keeps the most waves resident per CU
+  // (every workgroup holds its own copy of the scene in LDS, so fewer, larger groups win ties)
+  int threads = 0, bpc = 0;
+  uint32_t lds = 0;
+  const int forced = g_block_threads.load();
+  for (int t = (int)max_block_threads(prec); t >= 256; t -= 128) {
+    if (forced > 0 && t != forced) continue;
+    const uint32_t need = lds_bytes_needed(L, (uint32_t)t);
+    int b = render_blocks_per_cu(prec, counters, s->feat, t, need);
+    b = std::min(b, g_max_blocks_per_cu.load());
+    if (b * t > bpc * threads) { threads = t; bpc = b; lds = need; }
+  }
   if (bpc <= 0)
-    return fail(HT_E_TOO_LARGE, "the render kernel cannot be resident with %u bytes of LDS", lds);
-  bpc = std::min(bpc, g_max_blocks_per_cu.load());
+    return fail(HT_E_TOO_LARGE, "the render kernel cannot be resident with this scene (%u bytes of scene image)",
+                L.total_bytes);
   const int grid = bpc * s->n_cu;
 
   CameraBasis basis;
@@ -274,6 +295,9 @@ int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_para
   a.seed_lo = (uint32_t)p->seed;
   a.seed_hi = (uint32_t)(p->seed >> 32);
   a.wait_threshold = g_wait_threshold.load();
+  a.node_den = g_node_den.load();
+  a.wait_ratio_num = g_wait_num.load();
+  a.wait_ratio_den = g_wait_den.load();
 
   if (counters) HIP_TRY(hipMemsetAsync(s->d_counters, 0, NUM_COUNTERS * sizeof(unsigned long long), stream));
 
@@ -301,7 +325,7 @@ int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_para
     a.sample_first = p->sample_offset + done;
     a.sample_count = std::min(batch, p->samples - done);
     e = hipMemsetAsync(s->d_tile_counter, 0, 256, stream);
-    if (e == hipSuccess) e = launch_render(prec, counters, a, camp, grid, lds, stream);
+    if (e == hipSuccess) e = launch_render(prec, counters, s->feat, a, camp, grid, threads, lds, stream);
     if (e == hipSuccess) e = hipEventRecord(ev_batch[launches & 1], stream);
     launches++;
   }
@@ -345,6 +369,10 @@ int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_para
       cleanup();
       return fail(HT_E_HIP, "render failed on the device: %s", hipGetErrorString(e));
     }
+    stats->block_threads = threads;
+    stats->blocks_per_cu = bpc;
+    stats->lds_bytes = (int32_t)lds;
+    stats->n_cu = s->n_cu;
     stats->seconds_kernel = ms * 1e-3;
     stats->launches = launches;
     stats->samples = (int64_t)p->width * p->height * (cancelled ? (int64_t)(launches)*batch : p->samples);
@@ -468,9 +496,11 @@ int ht_first_hit(ht_scene* s, const ht_camera* cam, int32_t W, int32_t H, int32_
   a.t = d_t;
   a.prim = d_p;
   a.normal = d_n;
-  const uint32_t lds = lds_bytes_needed(a.L, precision);
+  uint32_t fh_threads = max_block_threads(precision);
+  while (fh_threads > 64 && lds_bytes_needed(a.L, fh_threads) > 160u * 1024u) fh_threads -= 64;
+  const uint32_t lds = lds_bytes_needed(a.L, fh_threads);
   e = launch_first_hit(precision, a, precision == HT_PRECISION_FP32 ? (const void*)&cam32 : (const void*)&cam64,
-                       lds, nullptr);
+                       (int)fh_threads, lds, nullptr);
   std::vector<uint8_t> ht_(n * rs), hn(n * 3 * rs);
   if (e == hipSuccess) e = hipMemcpy(ht_.data(), d_t, n * rs, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(hn.data(), d_n, n * 3 * rs, hipMemcpyDeviceToHost);

@@ -316,6 +316,14 @@ void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out) 
     bl.put<uint32_t>(L.images + i * 16 + 8, (uint32_t)((uint64_t)hs.image_offset[i] & 0xFFFFFFFFu));
     bl.put<uint32_t>(L.images + i * 16 + 12, (uint32_t)((uint64_t)hs.image_offset[i] >> 32));
   }
+  L.n_hoist = (uint32_t)hs.hoist.size();
+  L.hoist = bl.reserve((size_t)L.n_hoist * 4);
+  for (uint32_t i = 0; i < L.n_hoist; ++i) bl.put<uint32_t>(L.hoist + i * 4, hs.hoist[i]);
+  L.root_box = bl.reserve(8 * RS);
+  for (int a = 0; a < 3; ++a) {
+    bl.put<R>(L.root_box + a * RS, round_down<R>(hs.root_lo[a]));
+    bl.put<R>(L.root_box + (3 + a) * RS, round_up<R>(hs.root_hi[a]));
+  }
   L.total_bytes = bl.reserve(0);
   out.resize(L.total_bytes);
 }
@@ -464,27 +472,75 @@ int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err) {
     hs.prim_ref[p] = REF_LEAF | ((big ? KIND_BIG_SPHERE : KIND_SPHERE) << REF_KIND_SHIFT) | (uint32_t)i;
   }
 
-  // ---- hierarchy ---------------------------------------------------------------
-  std::vector<Item> items(n);
-  for (int p = 0; p < n; ++p) {
-    items[p].box = boxes[p];
-    for (int a = 0; a < 3; ++a) items[p].c[a] = 0.5 * (boxes[p].lo[a] + boxes[p].hi[a]);
-    items[p].ref = hs.prim_ref[p];
+  // ---- hoisted primitives + hierarchy ---------------------------------------------
+  // A primitive whose box covers most of the scene (a ground sphere, a room wall)
+  // gains nothing from a hierarchy: every ray reaches it anyway.  Such primitives,
+  // and ALL primitives of a tiny scene, are tested linearly by every ray at ray
+  // start, where all lanes of a wave run the same code on the same primitive; the
+  // BVH holds the rest.
+  constexpr int MAX_HOIST = 8;
+  std::vector<int> in_bvh;
+  hs.hoist.clear();
+  if (n <= MAX_HOIST) {
+    for (int p = 0; p < n; ++p) hs.hoist.push_back(hs.prim_ref[p]);
+  } else {
+    Box all;
+    all.reset();
+    for (int p = 0; p < n; ++p) all.grow(boxes[p]);
+    // the scene box without the very large primitives would be the honest yardstick,
+    // but the median primitive size does as well and needs no iteration
+    std::vector<double> areas(n);
+    for (int p = 0; p < n; ++p) areas[p] = boxes[p].half_area();
+    std::vector<double> sorted = areas;
+    std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+    const double median = sorted[n / 2];
+    std::vector<int> order(n);
+    for (int p = 0; p < n; ++p) order[p] = p;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return areas[a] > areas[b]; });
+    std::vector<uint8_t> hoisted(n, 0);
+    for (int k = 0; k < n && (int)hs.hoist.size() < MAX_HOIST; ++k) {
+      int p = order[k];
+      if (areas[p] >= 0.25 * all.half_area() && areas[p] > 1e4 * median) {
+        hoisted[p] = 1;
+      } else {
+        break;
+      }
+    }
+    for (int p = 0; p < n; ++p) {  // keep primitive order inside the hoist list
+      if (hoisted[p]) hs.hoist.push_back(hs.prim_ref[p]);
+      else in_bvh.push_back(p);
+    }
+  }
+  const int nb = (int)in_bvh.size();
+  std::vector<Item> items(nb);
+  Box root;
+  root.reset();
+  for (int k = 0; k < nb; ++k) {
+    int p = in_bvh[k];
+    items[k].box = boxes[p];
+    for (int a = 0; a < 3; ++a) items[k].c[a] = 0.5 * (boxes[p].lo[a] + boxes[p].hi[a]);
+    items[k].ref = hs.prim_ref[p];
+    root.grow(boxes[p]);
   }
   hs.nodes.clear();
-  if (n == 1) {
+  hs.depth = 0;
+  if (nb == 1) {
     // like the reference's BVH(only, only) (BVH.scala:30): the same leaf twice
     BvhNode nd;
     for (int c = 0; c < 2; ++c)
-      for (int a = 0; a < 3; ++a) { nd.lo[c][a] = boxes[0].lo[a]; nd.hi[c][a] = boxes[0].hi[a]; }
+      for (int a = 0; a < 3; ++a) { nd.lo[c][a] = items[0].box.lo[a]; nd.hi[c][a] = items[0].box.hi[a]; }
     nd.child[0] = nd.child[1] = items[0].ref;
     hs.nodes.push_back(nd);
     hs.depth = 1;
-  } else {
+  } else if (nb > 1) {
     Builder b{hs, items};
-    Box root;
-    b.build(0, n, STACK_MAX_DEPTH, 0, root);
+    Box rb;
+    b.build(0, nb, STACK_MAX_DEPTH, 0, rb);
     hs.depth = b.max_level;
+  }
+  for (int a = 0; a < 3; ++a) {
+    hs.root_lo[a] = nb ? root.lo[a] : 0.0;
+    hs.root_hi[a] = nb ? root.hi[a] : 0.0;
   }
   if (hs.nodes.size() > MAX_NODES) { err = "too many BVH nodes"; return HT_E_TOO_LARGE; }
 

@@ -36,7 +36,9 @@ struct HostScene {
   std::vector<uint8_t> sph_big;     // KIND_BIG_SPHERE flag per entry of sph
   std::vector<uint32_t> prim_ref;   // leaf reference of every primitive
 
-  std::vector<BvhNode> nodes;
+  std::vector<uint32_t> hoist;      // leaf references every ray tests linearly (not in the BVH)
+  std::vector<BvhNode> nodes;       // hierarchy over the remaining primitives (may be empty)
+  double root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
   int depth = 0;
 
   SceneLayout layout32{}, layout64{};

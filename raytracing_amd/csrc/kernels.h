@@ -30,6 +30,8 @@ struct RenderArgs {
   int32_t jitter;
   uint32_t seed_lo, seed_hi;
   int32_t wait_threshold;  // lanes that may wait for shading before traversal yields
+  int32_t node_den;        // node steps go on while inner lanes * node_den >= travelling lanes
+  int32_t wait_ratio_num, wait_ratio_den;  // traversal also yields when waiting/travelling >= num/den
 };
 
 struct FirstHitArgs {
@@ -54,16 +56,20 @@ enum {
 constexpr int BLOCK_THREADS = 1024;
 constexpr int TILE_W = 8, TILE_H = 8;
 
-// dynamic LDS bytes a render / first-hit launch needs for layout L
-uint32_t lds_bytes_needed(const SceneLayout& L, int precision);
+// dynamic LDS bytes a render / first-hit launch of `threads` threads needs for layout L
+uint32_t lds_bytes_needed(const SceneLayout& L, uint32_t threads);
+uint32_t max_block_threads(int precision);
 
-// Returns the number of workgroups per CU the device can hold for this kernel
-// and LDS size (0: does not fit).
-int render_blocks_per_cu(int precision, bool counters, uint32_t lds_bytes);
+// texture features a kernel variant is built for
+constexpr uint32_t KFEAT_PERLIN = 1u, KFEAT_IMAGE = 2u;
 
-hipError_t launch_render(int precision, bool counters, const RenderArgs& a, const void* cam,
-                         int grid_blocks, uint32_t lds_bytes, hipStream_t stream);
-hipError_t launch_first_hit(int precision, const FirstHitArgs& a, const void* cam,
+// Number of workgroups of `threads` threads per CU the device can hold for this
+// kernel variant and LDS size (0: does not fit).
+int render_blocks_per_cu(int precision, bool counters, uint32_t feat, int threads, uint32_t lds_bytes);
+
+hipError_t launch_render(int precision, bool counters, uint32_t feat, const RenderArgs& a, const void* cam,
+                         int grid_blocks, int threads, uint32_t lds_bytes, hipStream_t stream);
+hipError_t launch_first_hit(int precision, const FirstHitArgs& a, const void* cam, int threads,
                             uint32_t lds_bytes, hipStream_t stream);
 // mean + Vec3.toRGB + row flip (Vec3.scala:82-84, main.scala:93)
 hipError_t launch_resolve(const long long* accum, int32_t W, int32_t H, double inv_samples,

@@ -316,83 +316,119 @@ __device__ __forceinline__ void tri_solve(const TriGeom<R>& g, const Ray<R>& ray
   v = -dot(g.e1, dao) * inv_det;
 }
 
-// One traversal step of one lane: an inner node (two child boxes) or a leaf
-// (one primitive), then advance to the next reference (descend or pop).
+// One primitive against the ray; a closer accepted hit replaces tv.best_*.
 template <typename R, bool CNT>
-__device__ __forceinline__ void trav_step(const Scene& sc, const Ray<R>& ray, Trav<R>& tv,
+__device__ __forceinline__ void prim_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t ref,
+                                          R t_min, Cnt& cnt) {
+  const uint32_t kind = (ref >> REF_KIND_SHIFT) & 7u, idx = ref & REF_INDEX_MASK;
+  if (kind == KIND_SPHERE || kind == KIND_BIG_SPHERE) {
+    if (CNT) cnt.v[CTR_SPHERE]++;
+    SphereSolve<R> ss;
+    if (sphere_solve<R>(sc, ray, kind, idx, ss)) {
+      R t = (ss.t1 > t_min) ? ss.t1 : ss.t2;
+      if (t > t_min && t < tv.best_t) { tv.best_t = t; tv.best_ref = ref; }
+    }
+  } else if (kind == KIND_TRIANGLE) {
+    if (CNT) cnt.v[CTR_TRI]++;
+    TriGeom<R> g = load_tri<R>(sc, idx);
+    R det, t, u, v;
+    tri_solve<R>(g, ray, det, t, u, v);
+    R w = (R)1 - u - v;
+    if (det > (R)1e-6 && t >= t_min && t < tv.best_t && u >= (R)0 && v >= (R)0 && w >= (R)0) {
+      tv.best_t = t;
+      tv.best_ref = ref;
+    }
+  } else {  // XY / XZ / YZ rect, Hittable.scala:55-92
+    if (CNT) cnt.v[CTR_RECT]++;
+    RectGeom<R> g = load_rect<R>(sc, idx);
+    R oa, ob, ok, da, db, dk;
+    rect_axes<R>(kind, ray.o, oa, ob, ok);
+    rect_axes<R>(kind, ray.d, da, db, dk);
+    R t = (g.k - ok) * M<R>::rcp(dk);
+    R a = oa + t * da, bb = ob + t * db;
+    if (t >= t_min && t < tv.best_t && a >= g.a0 && a <= g.a1 && bb >= g.b0 && bb <= g.b1) {
+      tv.best_t = t;
+      tv.best_ref = ref;
+    }
+  }
+}
+
+// Next reference from the lane's stack whose entry distance is still in front of
+// the closest hit; REF_EMPTY when the stack runs out.
+template <typename R>
+__device__ __forceinline__ uint32_t trav_pop(Trav<R>& tv, const uint32_t* stack_lane) {
+  const uint32_t BT = blockDim.x;  // stack layout is [level][thread]
+  while (tv.sp > 0) {
+    tv.sp--;
+    const uint32_t e = stack_lane[tv.sp * BT];
+    const R tn = (R)__uint_as_float(e & 0xFFFF0000u);
+    if (tn < tv.best_t) return e & 0xFFFFu;
+  }
+  return REF_EMPTY;
+}
+
+// Inner node: slab-test both children, descend into the nearer one that is hit
+// and push the other, or pop when neither is.
+template <typename R, bool CNT>
+__device__ __forceinline__ void node_step(const Scene& sc, const Ray<R>& ray, Trav<R>& tv,
                                           uint32_t* stack_lane, R t_min, Cnt& cnt) {
-  constexpr uint32_t BT = M<R>::BT;
-  const uint32_t cur = tv.cur;
-  uint32_t next = REF_EMPTY;
-  bool need_pop = true;
-  if (!(cur & REF_LEAF)) {
-    R b[12];
-    uint32_t cc;
-    load_node<R>(sc, cur, b, cc);
-    R tn0, tn1;
-    bool h0 = slab<R>(ray, b[0], b[1], b[2], b[3], b[4], b[5], t_min, tv.best_t, tn0);
-    bool h1 = slab<R>(ray, b[6], b[7], b[8], b[9], b[10], b[11], t_min, tv.best_t, tn1);
-    uint32_t c0 = cc & 0xFFFFu, c1 = cc >> 16;
-    if (CNT) cnt.v[CTR_BOX] += 2;
-    if (h0 && h1) {
-      bool swp = tn1 < tn0;
-      uint32_t nearc = swp ? c1 : c0, farc = swp ? c0 : c1;
-      R tfar = swp ? tn0 : tn1;
-      uint32_t e = (__float_as_uint(M<R>::to_float_down(tfar)) & 0xFFFF0000u) | farc;
-      stack_lane[tv.sp * BT] = e;
-      tv.sp++;
-      next = nearc;
-      need_pop = false;
-    } else if (h0 || h1) {
-      next = h0 ? c0 : c1;
-      need_pop = false;
-    }
+  const uint32_t BT = blockDim.x;
+  R b[12];
+  uint32_t cc;
+  load_node<R>(sc, tv.cur, b, cc);
+  R tn0, tn1;
+  const bool h0 = slab<R>(ray, b[0], b[1], b[2], b[3], b[4], b[5], t_min, tv.best_t, tn0);
+  const bool h1 = slab<R>(ray, b[6], b[7], b[8], b[9], b[10], b[11], t_min, tv.best_t, tn1);
+  const uint32_t c0 = cc & 0xFFFFu, c1 = cc >> 16;
+  if (CNT) cnt.v[CTR_BOX] += 2;
+  if (h0 && h1) {
+    const bool swp = tn1 < tn0;
+    const uint32_t nearc = swp ? c1 : c0, farc = swp ? c0 : c1;
+    const R tfar = swp ? tn0 : tn1;
+    stack_lane[tv.sp * BT] = (__float_as_uint(M<R>::to_float_down(tfar)) & 0xFFFF0000u) | farc;
+    tv.sp++;
+    tv.cur = nearc;
+  } else if (h0 || h1) {
+    tv.cur = h0 ? c0 : c1;
   } else {
-    const uint32_t kind = (cur >> REF_KIND_SHIFT) & 7u, idx = cur & REF_INDEX_MASK;
-    if (kind == KIND_SPHERE || kind == KIND_BIG_SPHERE) {
-      if (CNT) cnt.v[CTR_SPHERE]++;
-      SphereSolve<R> ss;
-      if (sphere_solve<R>(sc, ray, kind, idx, ss)) {
-        R t = (ss.t1 > t_min) ? ss.t1 : ss.t2;
-        if (t > t_min && t < tv.best_t) { tv.best_t = t; tv.best_ref = cur; }
-      }
-    } else if (kind == KIND_TRIANGLE) {
-      if (CNT) cnt.v[CTR_TRI]++;
-      TriGeom<R> g = load_tri<R>(sc, idx);
-      R det, t, u, v;
-      tri_solve<R>(g, ray, det, t, u, v);
-      R w = (R)1 - u - v;
-      if (det > (R)1e-6 && t >= t_min && t < tv.best_t && u >= (R)0 && v >= (R)0 && w >= (R)0) {
-        tv.best_t = t;
-        tv.best_ref = cur;
-      }
-    } else {  // XY / XZ / YZ rect, Hittable.scala:55-92
-      if (CNT) cnt.v[CTR_RECT]++;
-      RectGeom<R> g = load_rect<R>(sc, idx);
-      R oa, ob, ok, da, db, dk;
-      rect_axes<R>(kind, ray.o, oa, ob, ok);
-      rect_axes<R>(kind, ray.d, da, db, dk);
-      R t = (g.k - ok) * M<R>::rcp(dk);
-      R a = oa + t * da, bb = ob + t * db;
-      if (t >= t_min && t < tv.best_t && a >= g.a0 && a <= g.a1 && bb >= g.b0 && bb <= g.b1) {
-        tv.best_t = t;
-        tv.best_ref = cur;
-      }
+    tv.cur = trav_pop<R>(tv, stack_lane);
+  }
+}
+
+// Start of a ray: the hoisted primitives (the same primitive for every lane, so
+// the wave runs one code path), then the bounds of the hierarchy.
+template <typename R, bool CNT>
+__device__ __forceinline__ void ray_start(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, R t_min,
+                                          Cnt& cnt) {
+  trav_begin<R>(tv);
+  const uint32_t* hl = (const uint32_t*)(sc.base + sc.L.hoist);
+  for (uint32_t i = 0; i < sc.L.n_hoist; ++i) {
+    const uint32_t ref = __builtin_amdgcn_readfirstlane(hl[i]);
+    prim_test<R, CNT>(sc, ray, tv, ref, t_min, cnt);
+  }
+  tv.cur = REF_EMPTY;
+  if (sc.L.n_nodes != 0u) {
+    const R* rb = (const R*)(sc.base + sc.L.root_box);
+    R tn;
+    if (CNT) cnt.v[CTR_BOX]++;
+    if (slab<R>(ray, rb[0], rb[1], rb[2], rb[3], rb[4], rb[5], t_min, tv.best_t, tn)) tv.cur = 0u;
+  }
+}
+
+// The whole closest-hit query of one lane (first-hit kernel).
+template <typename R>
+__device__ __forceinline__ void trace_closest(const Scene& sc, const Ray<R>& ray, Trav<R>& tv,
+                                              uint32_t* stack_lane, R t_min) {
+  Cnt cnt;
+  ray_start<R, false>(sc, ray, tv, t_min, cnt);
+  while (tv.cur != REF_EMPTY) {
+    if (!(tv.cur & REF_LEAF)) {
+      node_step<R, false>(sc, ray, tv, stack_lane, t_min, cnt);
+    } else {
+      prim_test<R, false>(sc, ray, tv, tv.cur, t_min, cnt);
+      tv.cur = trav_pop<R>(tv, stack_lane);
     }
   }
-  if (need_pop) {
-    next = REF_EMPTY;
-    while (tv.sp > 0) {
-      tv.sp--;
-      uint32_t e = stack_lane[tv.sp * BT];
-      R tn = (R)__uint_as_float(e & 0xFFFF0000u);
-      if (tn < tv.best_t) {
-        next = e & 0xFFFFu;
-        break;
-      }
-    }
-  }
-  tv.cur = next;
 }
 
 // ---------------------------------------------------------------------------
@@ -518,7 +554,11 @@ __device__ __forceinline__ R perlin_turb(const Scene& sc, uint32_t table, V3<R> 
 }
 
 // texture(uv, p) (Texture.scala:13, 21-25, 90, 98-107)
-template <typename R, bool CNT>
+// FEAT: which texture kinds beyond SolidColor / Checker the scene uses; the others
+// are compiled out (the Perlin and Image paths alone cost ~50 VGPRs).
+constexpr uint32_t FEAT_PERLIN = 1u, FEAT_IMAGE = 2u;
+
+template <typename R, bool CNT, uint32_t FEAT>
 __device__ __forceinline__ V3<R> texture_eval(const Scene& sc, const uint32_t* __restrict__ texels,
                                               uint32_t tex, const Ray<R>& ray, const HitGeom<R>& h,
                                               Cnt& cnt) {
@@ -533,23 +573,28 @@ __device__ __forceinline__ V3<R> texture_eval(const Scene& sc, const uint32_t* _
       tex = (sines < (R)0) ? ((w3 >> 2) & 0x7FFFu) : (w3 >> 17);
       continue;
     }
-    if (kind == 2u) {  // Perlin
-      R g = (R)0.5 * ((R)1 + M<R>::sin(t.x * h.p.z + (R)10 * perlin_turb<R>(sc, (w3 >> 2) & 0x7FFFu, h.p)));
-      return mk<R>(g, g, g);
+    if constexpr ((FEAT & FEAT_PERLIN) != 0u) {
+      if (kind == 2u) {  // Perlin
+        R g = (R)0.5 * ((R)1 + M<R>::sin(t.x * h.p.z + (R)10 * perlin_turb<R>(sc, (w3 >> 2) & 0x7FFFu, h.p)));
+        return mk<R>(g, g, g);
+      }
     }
-    // Image: nearest texel, no linearisation (Texture.scala:98-107, Vec3.scala:36-40)
-    R u, v;
-    hit_uv<R>(sc, ray, h, u, v);
-    const uint32_t* im = (const uint32_t*)(sc.base + sc.L.images) + ((w3 >> 2) & 0x7FFFu) * 4u;
-    int width = (int)im[0], height = (int)im[1];
-    uint64_t off = (uint64_t)im[2] | ((uint64_t)im[3] << 32);
-    R uc = M<R>::fmin(M<R>::fmax(u, (R)0), (R)1);
-    R vc = (R)1 - M<R>::fmin(M<R>::fmax(v, (R)0), (R)1);
-    int ii = min(max((int)(uc * (R)width), 0), width - 1);
-    int jj = min(max((int)(vc * (R)height), 0), height - 1);
-    uint32_t rgb = texels[off + (uint64_t)jj * (uint64_t)width + (uint64_t)ii];
-    const R s = (R)(1.0 / 255.0);
-    return mk<R>((R)((rgb >> 16) & 0xFFu) * s, (R)((rgb >> 8) & 0xFFu) * s, (R)(rgb & 0xFFu) * s);
+    if constexpr ((FEAT & FEAT_IMAGE) != 0u) {
+      // Image: nearest texel, no linearisation (Texture.scala:98-107, Vec3.scala:36-40)
+      R u, v;
+      hit_uv<R>(sc, ray, h, u, v);
+      const uint32_t* im = (const uint32_t*)(sc.base + sc.L.images) + ((w3 >> 2) & 0x7FFFu) * 4u;
+      int width = (int)im[0], height = (int)im[1];
+      uint64_t off = (uint64_t)im[2] | ((uint64_t)im[3] << 32);
+      R uc = M<R>::fmin(M<R>::fmax(u, (R)0), (R)1);
+      R vc = (R)1 - M<R>::fmin(M<R>::fmax(v, (R)0), (R)1);
+      int ii = min(max((int)(uc * (R)width), 0), width - 1);
+      int jj = min(max((int)(vc * (R)height), 0), height - 1);
+      uint32_t rgb = texels[off + (uint64_t)jj * (uint64_t)width + (uint64_t)ii];
+      const R s = (R)(1.0 / 255.0);
+      return mk<R>((R)((rgb >> 16) & 0xFFu) * s, (R)((rgb >> 8) & 0xFFu) * s, (R)(rgb & 0xFFu) * s);
+    }
+    return mk<R>((R)0, (R)0, (R)0);  // a kind this kernel variant was not built for (host never selects it)
   }
 }
 
@@ -597,77 +642,91 @@ __device__ __forceinline__ void deposit(const Sink& k, V3<R> c) {
   }
 }
 
-// material.scatter + material.emit for the closest hit (Material.scala:9-55,
-// Camera.scala:29-33).  Returns true when the path continues with `ray`
-// replaced by the scattered ray and T multiplied by the attenuation.
-template <typename R, bool CNT>
-__device__ __forceinline__ bool shade_hit(const Scene& sc, const RenderArgs& A, Ray<R>& ray,
-                                          const Trav<R>& tv, V3<R>& T, const Sink& sink, uint32_t pixel,
-                                          uint32_t sample, uint32_t bounce, Cnt& cnt) {
+// What the shading of a hit leaves for the scatter step.
+template <typename R>
+struct Surface {
+  V3<R> p, n;     // Hit.position, Hit.normal (not normalised)
+  R param;        // roughness / ior
+  uint32_t mkind; // HT_MAT_*
+  bool front;     // Hit.front_face
+};
+
+// First half of material.scatter / emit for the closest hit (Material.scala:9-55,
+// Camera.scala:29-33): geometry, material record, texture.  Emission deposits and
+// ends the path (returns false); otherwise T is multiplied by the attenuation and
+// `sf` describes the surface for scatter_direction().
+template <typename R, bool CNT, uint32_t FEAT>
+__device__ __forceinline__ bool shade_surface(const Scene& sc, const RenderArgs& A, const Ray<R>& ray,
+                                              const Trav<R>& tv, V3<R>& T, const Sink& sink,
+                                              Surface<R>& sf, Cnt& cnt) {
   HitGeom<R> h = hit_geometry<R>(sc, ray, tv.best_t, tv.best_ref);
   typename M<R>::R4 m = load_r4<R>(sc, sc.L.mat, h.meta >> META_MAT_SHIFT);
   const uint32_t m0 = M<R>::bits_lo(m.x);
-  const uint32_t mkind = m0 & 15u, tex = m0 >> 4;
-  const R param = m.y;
-  if (CNT) cnt.v[CTR_SHADE0 + mkind]++;
-  const bool front = dot(ray.d, h.n_out) < (R)0;          // Hit.front_face
-  const V3<R> n = front ? h.n_out : -h.n_out;             // Hit.normal (not normalised)
-  V3<R> col = texture_eval<R, CNT>(sc, A.texels, tex, ray, h, cnt);
-  if (mkind == 3u) {  // Emission: never scatters, emits on both faces
-    deposit<R>(sink, T * (param * col));
+  const uint32_t tex = m0 >> 4;
+  sf.mkind = m0 & 15u;
+  sf.param = m.y;
+  if (CNT) cnt.v[CTR_SHADE0 + sf.mkind]++;
+  sf.front = dot(ray.d, h.n_out) < (R)0;          // Hit.front_face
+  sf.n = sf.front ? h.n_out : -h.n_out;           // Hit.normal (not normalised)
+  sf.p = h.p;
+  V3<R> col = texture_eval<R, CNT, FEAT>(sc, A.texels, tex, ray, h, cnt);
+  if (sf.mkind == 3u) {  // Emission: never scatters, emits on both faces
+    deposit<R>(sink, T * (sf.param * col));
     return false;
   }
-  uint32_t rnd[4];
-  philox4x32_10(pixel, sample, bounce, 0u, A.seed_lo, A.seed_hi, rnd);
-  V3<R> dir;
-  if (mkind == 0u) {  // Diffuse
-    dir = n + unit_vector_from<R>(u01<R>(rnd[0]), u01<R>(rnd[1]));
-  } else if (mkind == 1u) {  // Glossy
-    V3<R> ud = M<R>::rsqrt(ray.a) * ray.d;
-    V3<R> refl = ud - ((R)2 * dot(ud, n)) * n;
-    V3<R> ball = M<R>::cbrt(u01<R>(rnd[2])) * unit_vector_from<R>(u01<R>(rnd[0]), u01<R>(rnd[1]));
-    dir = refl + param * ball;
-    if (!(dot(dir, n) > (R)0)) return false;  // absorbed, emit = 0
-  } else {  // Glass
-    V3<R> ud = M<R>::rsqrt(ray.a) * ray.d;
-    R eta = front ? M<R>::rcp(param) : param;
-    R cos_theta = M<R>::fmin(-dot(ud, n), (R)1);
-    R sin_theta = M<R>::sqrt((R)1 - cos_theta * cos_theta);
-    bool reflect_it = eta * sin_theta > (R)1;
-    if (!reflect_it) {
-      R r0 = ((R)1 - eta) / ((R)1 + eta);
-      R r1 = r0 * r0;
-      R x = (R)1 - cos_theta;
-      R x2 = x * x;
-      R sch = r1 + ((R)1 - r1) * (x2 * x2 * x);
-      reflect_it = sch > u01<R>(rnd[0]);
-    }
-    if (reflect_it) {
-      dir = ud - ((R)2 * dot(ud, n)) * n;
-    } else {
-      R ct = -dot(ud, n);
-      V3<R> perp = eta * (ud + ct * n);
-      V3<R> par = (-M<R>::sqrt(M<R>::fabs((R)1 - dot(perp, perp)))) * n;
-      dir = perp + par;
-    }
-  }
   T = T * col;
-  ray.o = h.p;
-  ray.d = dir;
-  ray_setup<R>(ray);
   return true;
 }
 
-// Camera.get_ray (Camera.scala:19-23) for sample `sample` of pixel (i, j)
-// (main.scala:88-89).
+// Second half: the scattered direction from the event's four uniforms.
+// Returns false when a Glossy bounce is absorbed (Material.scala:18-19).
+template <typename R>
+__device__ __forceinline__ bool scatter_direction(const Surface<R>& sf, const Ray<R>& ray,
+                                                  const uint32_t rnd[4], V3<R>& dir) {
+  const V3<R> n = sf.n;
+  if (sf.mkind == 0u) {  // Diffuse
+    dir = n + unit_vector_from<R>(u01<R>(rnd[0]), u01<R>(rnd[1]));
+    return true;
+  }
+  const V3<R> ud = M<R>::rsqrt(ray.a) * ray.d;  // ray.direction.unit_vector
+  if (sf.mkind == 1u) {  // Glossy
+    V3<R> refl = ud - ((R)2 * dot(ud, n)) * n;
+    V3<R> ball = M<R>::cbrt(u01<R>(rnd[2])) * unit_vector_from<R>(u01<R>(rnd[0]), u01<R>(rnd[1]));
+    dir = refl + sf.param * ball;
+    return dot(dir, n) > (R)0;
+  }
+  // Glass
+  R eta = sf.front ? M<R>::rcp(sf.param) : sf.param;
+  R cos_theta = M<R>::fmin(-dot(ud, n), (R)1);
+  R sin_theta = M<R>::sqrt((R)1 - cos_theta * cos_theta);
+  bool reflect_it = eta * sin_theta > (R)1;
+  if (!reflect_it) {
+    R r0 = ((R)1 - eta) / ((R)1 + eta);
+    R r1 = r0 * r0;
+    R x = (R)1 - cos_theta;
+    R x2 = x * x;
+    R sch = r1 + ((R)1 - r1) * (x2 * x2 * x);
+    reflect_it = sch > u01<R>(rnd[0]);
+  }
+  if (reflect_it) {
+    dir = ud - ((R)2 * dot(ud, n)) * n;
+  } else {
+    R ct = -dot(ud, n);
+    V3<R> perp = eta * (ud + ct * n);
+    V3<R> par = (-M<R>::sqrt(M<R>::fabs((R)1 - dot(perp, perp)))) * n;
+    dir = perp + par;
+  }
+  return true;
+}
+
+// Camera.get_ray (Camera.scala:19-23) for one sample of pixel (i, j)
+// (main.scala:88-89); rnd = the path's camera event.
 template <typename R>
 __device__ __forceinline__ void camera_ray(const RenderArgs& A, const CamDev<R>& cam, Ray<R>& ray,
-                                           uint32_t i, uint32_t j, uint32_t pixel, uint32_t sample) {
+                                           uint32_t i, uint32_t j, const uint32_t rnd[4]) {
   R xi1 = (R)0.5, xi2 = (R)0.5;
   V3<R> offset = mk<R>((R)0, (R)0, (R)0);
   if (A.jitter) {
-    uint32_t rnd[4];
-    philox4x32_10(pixel, sample, 0u, 0u, A.seed_lo, A.seed_hi, rnd);
     xi1 = u01<R>(rnd[0]);
     xi2 = u01<R>(rnd[1]);
     // uniform point of the unit disk, scaled by the lens radius
@@ -681,7 +740,6 @@ __device__ __forceinline__ void camera_ray(const RenderArgs& A, const CamDev<R>&
   V3<R> origin = ld3<R>(cam.origin);
   ray.o = origin + offset;
   ray.d = ld3<R>(cam.llc) + s * ld3<R>(cam.horizontal) + t * ld3<R>(cam.vertical) - origin - offset;
-  ray_setup<R>(ray);
 }
 
 // ---------------------------------------------------------------------------
@@ -698,8 +756,9 @@ __device__ __forceinline__ void copy_scene_to_lds(uint8_t* lds, const uint8_t* b
 enum : uint32_t { ST_TRAV = 0, ST_WAIT = 1, ST_DEAD = 2, ST_DONE = 3 };
 
 // LDS of a render workgroup: [scene image][traversal stacks][per-wave tile sums]
+// (a lane pushes at most one entry per level of inner nodes above it)
 __host__ __device__ inline uint32_t stack_bytes(uint32_t threads, uint32_t depth) {
-  return threads * 4u * (depth + 1u);
+  return threads * 4u * (depth > 0u ? depth : 1u);
 }
 constexpr uint32_t TILE_PIXELS = TILE_W * TILE_H;       // 64 = one wave
 constexpr uint32_t TILE_ACC_BYTES = TILE_PIXELS * 3u * 8u;
@@ -710,10 +769,10 @@ constexpr uint32_t TILE_ACC_BYTES = TILE_PIXELS * 3u * 8u;
 // dead lanes claim the next (pixel, sample) items of the current unit, and when
 // the unit runs out the wave moves on to the next one at once while the
 // stragglers of the old unit are still in flight.
-template <typename R, bool CNT>
+template <typename R, bool CNT, uint32_t FEAT>
 __global__ void __launch_bounds__(M<R>::BT) render_kernel(RenderArgs A, CamDev<R> cam) {
   extern __shared__ __align__(16) uint8_t lds[];
-  constexpr uint32_t BT = M<R>::BT;
+  const uint32_t BT = blockDim.x;  // <= M<R>::BT, a multiple of 64
   copy_scene_to_lds(lds, A.blob, A.L.total_bytes, BT);
   Scene sc;
   sc.base = lds;
@@ -776,44 +835,44 @@ __global__ void __launch_bounds__(M<R>::BT) render_kernel(RenderArgs A, CamDev<R
   for (;;) {
     uint64_t ts0 = 0;
     if (CNT) ts0 = __builtin_amdgcn_s_memtime();
-    // ---- shade the lanes whose ray is finished --------------------------------
+    // ---- 1. shade the finished rays: deposit, or prepare a scatter ------------------
+    // A lane leaves this block as DEAD (path ended) or with `scatter` set.
     if (CNT) {
       const uint64_t w = __ballot(state == ST_WAIT);
       if (lane == 0 && w != 0ull) cnt.v[CTR_SHADE_ROUNDS]++;
     }
+    bool scatter = false;
+    Surface<R> sf;
+    sf.p = sf.n = mk<R>((R)0, (R)0, (R)0);
+    sf.param = (R)0;
+    sf.mkind = 0u;
+    sf.front = false;
     if (state == ST_WAIT) {
       Sink sink;
       sink.lds = tile_acc + pix * 3u;
       sink.global = frame + (size_t)pixel * 3u;
       sink.current = my_epoch == epoch;
-      bool cont;
+      state = ST_DEAD;
       if (tv.best_ref == REF_EMPTY) {
         deposit<R>(sink, T * bg);  // case None => background (Camera.scala:34)
-        cont = false;
         if (CNT) cnt.v[CTR_MISS]++;
-      } else {
-        cont = shade_hit<R, CNT>(sc, A, ray, tv, T, sink, pixel, sample, bounce, cnt);
-        // depth exhausted: the next ray_color call returns 0 (Camera.scala:27)
-        if (cont && bounce >= (uint32_t)A.max_depth) cont = false;
-      }
-      if (cont) {
-        bounce++;
-        trav_begin<R>(tv);
-        state = ST_TRAV;
-        if (CNT) cnt.v[CTR_RAYS]++;
-      } else {
-        state = ST_DEAD;
+      } else if (shade_surface<R, CNT, FEAT>(sc, A, ray, tv, T, sink, sf, cnt)) {
+        // depth exhausted: the scattered ray's ray_color returns 0 (Camera.scala:27),
+        // so the path contributes nothing more
+        scatter = bounce < (uint32_t)A.max_depth;
       }
     }
     uint64_t ts1 = 0;
     if (CNT) ts1 = __builtin_amdgcn_s_memtime();
-    // ---- dead lanes claim the next items and start their camera paths ---------------
+    // ---- 2. dead lanes claim the next (pixel, sample) items ---------------------------
+    bool camera = false;
+    uint32_t cpx = 0, cpy = 0;
     for (;;) {
-      const uint64_t dead = __ballot(state == ST_DEAD);
+      const uint64_t dead = __ballot(state == ST_DEAD && !scatter && !camera);
       if (dead == 0ull) break;
       if (next_item >= pool_size) {  // wave-uniform: the current unit is used up
         if (queue_empty) {
-          if (state == ST_DEAD) state = ST_DONE;
+          if (state == ST_DEAD && !scatter && !camera) state = ST_DONE;
           break;
         }
         if (epoch != 0u) flush_tile();
@@ -835,25 +894,47 @@ __global__ void __launch_bounds__(M<R>::BT) render_kernel(RenderArgs A, CamDev<R
         continue;
       }
       if (CNT && lane == 0) cnt.v[CTR_REGEN_ROUNDS]++;
-      if (state == ST_DEAD) {
+      if (state == ST_DEAD && !scatter && !camera) {
         const uint32_t item = next_item + (uint32_t)__popcll(dead & ((1ull << lane) - 1ull));
         if (item < pool_size) {
-          pix = item & (TILE_PIXELS - 1u);
-          const uint32_t px = tile_x0 + (pix & 7u), py = tile_y0 + (pix >> 3);
+          const uint32_t q = item & (TILE_PIXELS - 1u);
+          const uint32_t px = tile_x0 + (q & 7u), py = tile_y0 + (q >> 3);
           if (px < (uint32_t)A.W && py < (uint32_t)A.H) {  // else: claim again next round
+            pix = q;
+            cpx = px;
+            cpy = py;
             pixel = py * (uint32_t)A.W + px;
             sample = sample_base + (item >> 6);
             my_epoch = epoch;
-            camera_ray<R>(A, cam, ray, px, py, pixel, sample);
-            T = mk<R>((R)1, (R)1, (R)1);
-            bounce = 1;
-            trav_begin<R>(tv);
-            state = ST_TRAV;
-            if (CNT) cnt.v[CTR_RAYS]++;
+            bounce = 0;
+            camera = true;
           }
         }
       }
       next_item = min(pool_size, next_item + (uint32_t)__popcll(dead));
+    }
+    // ---- 3. one random event for every lane that starts a ray --------------------------
+    // (scatter event `bounce` of the path, or its camera event 0)
+    if (scatter || camera) {
+      uint32_t rnd[4];
+      philox4x32_10(pixel, sample, bounce, 0u, A.seed_lo, A.seed_hi, rnd);
+      bool go = true;
+      if (camera) {
+        camera_ray<R>(A, cam, ray, cpx, cpy, rnd);
+        T = mk<R>((R)1, (R)1, (R)1);
+      } else {
+        V3<R> dir;
+        go = scatter_direction<R>(sf, ray, rnd, dir);
+        ray.o = sf.p;
+        ray.d = dir;
+      }
+      if (go) {
+        bounce++;
+        ray_setup<R>(ray);
+        ray_start<R, CNT>(sc, ray, tv, t_min, cnt);
+        state = (tv.cur == REF_EMPTY) ? ST_WAIT : ST_TRAV;
+        if (CNT) cnt.v[CTR_RAYS]++;
+      }  // else: absorbed, the lane stays DEAD and claims new work next round
     }
     uint64_t ts2 = 0;
     if (CNT) {
@@ -863,18 +944,37 @@ __global__ void __launch_bounds__(M<R>::BT) render_kernel(RenderArgs A, CamDev<R
         cnt.v[CTR_CYC_REGEN] += (uint32_t)(ts2 - ts1);
       }
     }
-    if (__ballot(state == ST_TRAV) == 0ull) break;  // the queue is empty and every path ended
-    // ---- traversal, until enough lanes wait for shading --------------------------
-    for (;;) {
-      if (state == ST_TRAV) {
-        trav_step<R, CNT>(sc, ray, tv, stack_lane, t_min, cnt);
-        if (tv.cur == REF_EMPTY) state = ST_WAIT;
-        if (CNT) cnt.v[CTR_ACTIVE]++;
+    if (__ballot(state != ST_DONE) == 0ull) break;  // the queue is empty and every path ended
+    // ---- 4. traversal: node steps while most lanes are at inner nodes, then one leaf
+    //         step for the lanes that reached a primitive; until enough rays are done ----
+    while (__ballot(state == ST_TRAV) != 0ull) {
+      for (;;) {
+        const bool inner = state == ST_TRAV && !(tv.cur & REF_LEAF);
+        const uint64_t mi = __ballot(inner);
+        const uint64_t mt = __ballot(state == ST_TRAV);
+        // leaves wait while at least a third of the travelling lanes still descend
+        if (mi == 0ull || A.node_den * __popcll(mi) < __popcll(mt)) break;
+        if (inner) {
+          node_step<R, CNT>(sc, ray, tv, stack_lane, t_min, cnt);
+          if (tv.cur == REF_EMPTY) state = ST_WAIT;
+          if (CNT) cnt.v[CTR_ACTIVE]++;
+        }
+        if (CNT) cnt.v[CTR_STEPS]++;
       }
-      if (CNT) cnt.v[CTR_STEPS]++;
-      const uint64_t trav = __ballot(state == ST_TRAV);
-      const uint64_t wait = __ballot(state == ST_WAIT);
-      if (trav == 0ull || __popcll(wait) >= A.wait_threshold) break;
+      const bool leaf = state == ST_TRAV && (tv.cur & REF_LEAF);
+      if (__ballot(leaf) != 0ull) {
+        if (leaf) {
+          prim_test<R, CNT>(sc, ray, tv, tv.cur, t_min, cnt);
+          tv.cur = trav_pop<R>(tv, stack_lane);
+          if (tv.cur == REF_EMPTY) state = ST_WAIT;
+          if (CNT) cnt.v[CTR_ACTIVE]++;
+        }
+        if (CNT) cnt.v[CTR_STEPS]++;
+      }
+      {
+        const int nw = __popcll(__ballot(state == ST_WAIT)), nt = __popcll(__ballot(state == ST_TRAV));
+        if (nw >= A.wait_threshold || nw * A.wait_ratio_den >= nt * A.wait_ratio_num) break;
+      }
     }
     if (CNT && lane == 0) cnt.v[CTR_CYC_TRAV] += (uint32_t)(__builtin_amdgcn_s_memtime() - ts2);
   }
@@ -903,7 +1003,7 @@ __global__ void __launch_bounds__(M<R>::BT) render_kernel(RenderArgs A, CamDev<R
 template <typename R>
 __global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, CamDev<R> cam) {
   extern __shared__ __align__(16) uint8_t lds[];
-  constexpr uint32_t BT = M<R>::BT;
+  const uint32_t BT = blockDim.x;
   copy_scene_to_lds(lds, A.blob, A.L.total_bytes, BT);
   Scene sc;
   sc.base = lds;
@@ -923,15 +1023,12 @@ __global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, Cam
   ra.jitter = 0;
   ra.W = A.W;
   ra.H = A.H;
-  ra.seed_lo = ra.seed_hi = 0;
-  CamDev<R> c = cam;
-  c.lens_radius = (R)0;
+  const uint32_t no_rnd[4] = {0u, 0u, 0u, 0u};
   Ray<R> ray;
-  camera_ray<R>(ra, c, ray, px, py, pixel, 0u);
+  camera_ray<R>(ra, cam, ray, px, py, no_rnd);  // jitter off: pixel centre, lens closed
+  ray_setup<R>(ray);
   Trav<R> tv;
-  trav_begin<R>(tv);
-  Cnt cnt;
-  while (tv.cur != REF_EMPTY) trav_step<R, false>(sc, ray, tv, stack_lane, (R)0.001, cnt);
+  trace_closest<R>(sc, ray, tv, stack_lane, (R)0.001);
 
   R* t_out = (R*)A.t;
   R* n_out = (R*)A.normal;
@@ -975,10 +1072,10 @@ __global__ void resolve_kernel(const long long* __restrict__ accum, int32_t W, i
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
-uint32_t lds_bytes_needed(const SceneLayout& L, int precision) {
-  const uint32_t bt = precision == 0 ? M<float>::BT : M<double>::BT;
-  return L.total_bytes + stack_bytes(bt, L.depth) + (bt / 64u) * TILE_ACC_BYTES;
+uint32_t lds_bytes_needed(const SceneLayout& L, uint32_t threads) {
+  return L.total_bytes + stack_bytes(threads, L.depth) + (threads / 64u) * TILE_ACC_BYTES;
 }
+uint32_t max_block_threads(int precision) { return precision == 0 ? M<float>::BT : M<double>::BT; }
 
 template <typename K>
 static hipError_t allow_big_lds(K kernel, uint32_t lds_bytes) {
@@ -986,66 +1083,66 @@ static hipError_t allow_big_lds(K kernel, uint32_t lds_bytes) {
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 }
 
-template <typename K>
-static int blocks_per_cu(K kernel, int threads, uint32_t lds_bytes) {
-  if (allow_big_lds(kernel, lds_bytes) != hipSuccess) {
+namespace {
+typedef void (*RenderKernel32)(RenderArgs, CamDev<float>);
+typedef void (*RenderKernel64)(RenderArgs, CamDev<double>);
+// [counters][feat]
+const RenderKernel32 k32[2][4] = {
+    {render_kernel<float, false, 0>, render_kernel<float, false, 1>, render_kernel<float, false, 2>,
+     render_kernel<float, false, 3>},
+    {render_kernel<float, true, 0>, render_kernel<float, true, 1>, render_kernel<float, true, 2>,
+     render_kernel<float, true, 3>}};
+const RenderKernel64 k64[2][4] = {
+    {render_kernel<double, false, 0>, render_kernel<double, false, 1>, render_kernel<double, false, 2>,
+     render_kernel<double, false, 3>},
+    {render_kernel<double, true, 0>, render_kernel<double, true, 1>, render_kernel<double, true, 2>,
+     render_kernel<double, true, 3>}};
+const void* render_kernel_ptr(int precision, bool counters, uint32_t feat) {
+  return precision == 0 ? reinterpret_cast<const void*>(k32[counters ? 1 : 0][feat & 3u])
+                        : reinterpret_cast<const void*>(k64[counters ? 1 : 0][feat & 3u]);
+}
+}  // namespace
+
+int render_blocks_per_cu(int precision, bool counters, uint32_t feat, int threads, uint32_t lds_bytes) {
+  const void* k = render_kernel_ptr(precision, counters, feat);
+  if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kernel), threads,
-                                                   lds_bytes) != hipSuccess) {
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, threads, lds_bytes) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
   return n;
 }
 
-int render_blocks_per_cu(int precision, bool counters, uint32_t lds_bytes) {
-  if (precision == 0)
-    return counters ? blocks_per_cu(render_kernel<float, true>, M<float>::BT, lds_bytes)
-                    : blocks_per_cu(render_kernel<float, false>, M<float>::BT, lds_bytes);
-  return counters ? blocks_per_cu(render_kernel<double, true>, M<double>::BT, lds_bytes)
-                  : blocks_per_cu(render_kernel<double, false>, M<double>::BT, lds_bytes);
-}
-
-hipError_t launch_render(int precision, bool counters, const RenderArgs& a, const void* cam,
-                         int grid_blocks, uint32_t lds_bytes, hipStream_t stream) {
+hipError_t launch_render(int precision, bool counters, uint32_t feat, const RenderArgs& a, const void* cam,
+                         int grid_blocks, int threads, uint32_t lds_bytes, hipStream_t stream) {
   if (precision == 0) {
-    const CamDev<float>& c = *static_cast<const CamDev<float>*>(cam);
-    if (counters)
-      hipLaunchKernelGGL((render_kernel<float, true>), dim3(grid_blocks), dim3(M<float>::BT), lds_bytes,
-                         stream, a, c);
-    else
-      hipLaunchKernelGGL((render_kernel<float, false>), dim3(grid_blocks), dim3(M<float>::BT), lds_bytes,
-                         stream, a, c);
+    hipLaunchKernelGGL(k32[counters ? 1 : 0][feat & 3u], dim3(grid_blocks), dim3(threads), lds_bytes, stream,
+                       a, *static_cast<const CamDev<float>*>(cam));
   } else {
-    const CamDev<double>& c = *static_cast<const CamDev<double>*>(cam);
-    if (counters)
-      hipLaunchKernelGGL((render_kernel<double, true>), dim3(grid_blocks), dim3(M<double>::BT),
-                         lds_bytes, stream, a, c);
-    else
-      hipLaunchKernelGGL((render_kernel<double, false>), dim3(grid_blocks), dim3(M<double>::BT),
-                         lds_bytes, stream, a, c);
+    hipLaunchKernelGGL(k64[counters ? 1 : 0][feat & 3u], dim3(grid_blocks), dim3(threads), lds_bytes, stream,
+                       a, *static_cast<const CamDev<double>*>(cam));
   }
   return hipGetLastError();
 }
 
-hipError_t launch_first_hit(int precision, const FirstHitArgs& a, const void* cam, uint32_t lds_bytes,
-                            hipStream_t stream) {
+hipError_t launch_first_hit(int precision, const FirstHitArgs& a, const void* cam, int threads,
+                            uint32_t lds_bytes, hipStream_t stream) {
   const uint32_t tiles = (uint32_t)((a.W + TILE_W - 1) / TILE_W) * (uint32_t)((a.H + TILE_H - 1) / TILE_H);
+  const uint32_t wpb = (uint32_t)threads / 64u;
   if (precision == 0) {
     hipError_t e = allow_big_lds(first_hit_kernel<float>, lds_bytes);
     if (e != hipSuccess) return e;
-    const uint32_t wpb = M<float>::BT / 64;
-    hipLaunchKernelGGL((first_hit_kernel<float>), dim3((tiles + wpb - 1) / wpb), dim3(M<float>::BT),
-                       lds_bytes, stream, a, *static_cast<const CamDev<float>*>(cam));
+    hipLaunchKernelGGL((first_hit_kernel<float>), dim3((tiles + wpb - 1) / wpb), dim3(threads), lds_bytes,
+                       stream, a, *static_cast<const CamDev<float>*>(cam));
   } else {
     hipError_t e = allow_big_lds(first_hit_kernel<double>, lds_bytes);
     if (e != hipSuccess) return e;
-    const uint32_t wpb = M<double>::BT / 64;
-    hipLaunchKernelGGL((first_hit_kernel<double>), dim3((tiles + wpb - 1) / wpb), dim3(M<double>::BT),
-                       lds_bytes, stream, a, *static_cast<const CamDev<double>*>(cam));
+    hipLaunchKernelGGL((first_hit_kernel<double>), dim3((tiles + wpb - 1) / wpb), dim3(threads), lds_bytes,
+                       stream, a, *static_cast<const CamDev<double>*>(cam));
   }
   return hipGetLastError();
 }

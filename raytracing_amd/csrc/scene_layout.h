@@ -65,8 +65,10 @@ struct SceneLayout {
   uint32_t perlin;      // n_perlin * perlin_stride: 256 * 4R gradients, then 3*256 bytes perm
   uint32_t perlin_stride;
   uint32_t images;      // n_images * 4 u32 {width, height, offset_lo, offset_hi}
+  uint32_t hoist;       // n_hoist * u32 leaf references tested by every ray before the BVH
+  uint32_t root_box;    // 6R: bounds of everything inside the BVH (lo.xyz, hi.xyz)
   uint32_t total_bytes; // multiple of 16
-  uint32_t n_nodes, n_sph, n_rect, n_tri, n_mat, n_tex, n_perlin, n_images;
+  uint32_t n_nodes, n_sph, n_rect, n_tri, n_mat, n_tex, n_perlin, n_images, n_hoist;
   uint32_t depth;       // levels of traversal stack needed
   uint32_t has_uv_textures; // any Image texture in the scene
 };
