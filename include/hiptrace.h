@@ -229,6 +229,27 @@ int ht_resolve_device(ht_scene* scene, const int64_t* accum_dev, int32_t width, 
                       int64_t total_samples, float* rgb_linear_dev, uint32_t* rgb_packed_dev,
                       void* stream);
 
+/* A frame: a device accumulation buffer owned by the library, for callers that
+ * cannot allocate device memory themselves (a JVM host) and for progressive
+ * rendering.  The reference's renderFrame fills its BufferedImage in one go
+ * (main.scala:79-96); with a frame the host adds sample batches, reads the picture
+ * after any of them (the GUI's live view, main.scala:181) and can stop between
+ * batches (shouldBreak, main.scala:80). */
+typedef struct ht_frame ht_frame; /* opaque */
+int ht_frame_create(ht_scene* scene, int32_t width, int32_t height, ht_frame** out);
+void ht_frame_destroy(ht_frame* frame);
+/* Forget all samples (the sums become zero). */
+int ht_frame_clear(ht_frame* frame);
+/* Add params->samples paths per pixel starting at global sample index
+ * params->sample_offset; width / height must match the frame.  Synchronous. */
+int ht_frame_accumulate(ht_frame* frame, const ht_camera* camera, const ht_render_params* params,
+                        ht_stats* stats_out);
+/* The picture of everything accumulated so far (host buffers as in ht_render;
+ * either may be NULL).  Fails with HT_E_INVALID while the frame holds no samples. */
+int ht_frame_read(ht_frame* frame, float* rgb_linear, uint32_t* rgb_packed);
+/* Samples per pixel accumulated so far. */
+int64_t ht_frame_samples(const ht_frame* frame);
+
 /* First-hit buffers with jitter off (u = (i+0.5)/(W-1), v = (j+0.5)/(H-1),
  * aperture forced to 0): what world.hit(ray, 0.001, +inf) returns for the
  * camera ray of every pixel (Camera.scala:28, BVH.scala:7-14).

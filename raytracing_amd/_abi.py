@@ -135,6 +135,12 @@ EXPORTS = [
     "ht_render_accumulate",
     "ht_resolve",
     "ht_resolve_device",
+    "ht_frame_create",
+    "ht_frame_destroy",
+    "ht_frame_clear",
+    "ht_frame_accumulate",
+    "ht_frame_read",
+    "ht_frame_samples",
     "ht_first_hit",
     "ht_cancel",
     "ht_last_error",

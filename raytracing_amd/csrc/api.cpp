@@ -34,6 +34,13 @@ struct ht_scene {
   uint32_t feat = 0;  // KFEAT_* texture kinds present in the scene
 };
 
+struct ht_frame {
+  ht_scene* scene = nullptr;
+  int32_t width = 0, height = 0;
+  int64_t samples = 0;
+  int64_t* d_accum = nullptr;
+};
+
 namespace {
 
 thread_local std::string g_error;
@@ -456,6 +463,72 @@ int ht_render(ht_scene* s, const ht_camera* cam, const ht_render_params* p, floa
   }
   return rc;
 }
+
+int ht_frame_create(ht_scene* s, int32_t W, int32_t H, ht_frame** out) {
+  if (!s || !out) return fail(HT_E_INVALID, "NULL argument");
+  *out = nullptr;
+  if (W < 2 || H < 2)
+    return fail(HT_E_INVALID, "width and height must be >= 2 (the reference divides by W-1 and H-1)");
+  if ((int64_t)W * H > (int64_t)1 << 30) return fail(HT_E_INVALID, "image too large");
+  DeviceGuard g(s->device);
+  if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
+  ht_frame* f = new (std::nothrow) ht_frame;
+  if (!f) return fail(HT_E_INVALID, "out of host memory");
+  f->scene = s;
+  f->width = W;
+  f->height = H;
+  const size_t bytes = (size_t)W * H * 3 * sizeof(int64_t);
+  hipError_t e = hipMalloc((void**)&f->d_accum, bytes);
+  if (e == hipSuccess) e = hipMemset(f->d_accum, 0, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    if (f->d_accum) (void)hipFree(f->d_accum);
+    delete f;
+    return fail(HT_E_HIP, "frame allocation failed: %s", hipGetErrorString(e));
+  }
+  *out = f;
+  return HT_OK;
+}
+
+void ht_frame_destroy(ht_frame* f) {
+  if (!f) return;
+  {
+    DeviceGuard g(f->scene->device);
+    if (f->d_accum) (void)hipFree(f->d_accum);
+  }
+  delete f;
+}
+
+int ht_frame_clear(ht_frame* f) {
+  if (!f) return fail(HT_E_INVALID, "frame is NULL");
+  DeviceGuard g(f->scene->device);
+  if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", f->scene->device);
+  HIP_TRY(hipMemset(f->d_accum, 0, (size_t)f->width * f->height * 3 * sizeof(int64_t)));
+  f->samples = 0;
+  return HT_OK;
+}
+
+int ht_frame_accumulate(ht_frame* f, const ht_camera* cam, const ht_render_params* p, ht_stats* stats_out) {
+  if (!f || !p) return fail(HT_E_INVALID, "NULL argument");
+  if (p->width != f->width || p->height != f->height)
+    return fail(HT_E_INVALID, "params are %dx%d, the frame is %dx%d", p->width, p->height, f->width, f->height);
+  ht_stats st;
+  int rc = ht_render_accumulate(f->scene, cam, p, f->d_accum, nullptr, &st);
+  if (rc == HT_OK || rc == HT_E_CANCELLED) {
+    // a cancelled call still added the batches it had launched
+    f->samples += st.samples / ((int64_t)f->width * f->height);
+    if (stats_out) *stats_out = st;
+  }
+  return rc;
+}
+
+int ht_frame_read(ht_frame* f, float* rgb_linear, uint32_t* rgb_packed) {
+  if (!f) return fail(HT_E_INVALID, "frame is NULL");
+  if (f->samples < 1) return fail(HT_E_INVALID, "the frame holds no samples yet");
+  return ht_resolve(f->scene, f->d_accum, f->width, f->height, f->samples, rgb_linear, rgb_packed, nullptr);
+}
+
+int64_t ht_frame_samples(const ht_frame* f) { return f ? f->samples : 0; }
 
 int ht_first_hit(ht_scene* s, const ht_camera* cam, int32_t W, int32_t H, int32_t precision,
                  float* t, int32_t* prim_id, float* normal, double* t64, double* normal64) {

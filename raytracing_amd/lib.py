@@ -55,6 +55,15 @@ def load() -> C.CDLL:
     L.ht_cancel.argtypes = [vp]
     L.ht_scene_get_info.argtypes = [vp, C.POINTER(A.ht_scene_info)]
     L.ht_set_option.argtypes = [C.c_char_p, C.c_int]
+    L.ht_frame_create.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.ht_frame_destroy.argtypes = [vp]
+    L.ht_frame_destroy.restype = None
+    L.ht_frame_clear.argtypes = [vp]
+    L.ht_frame_accumulate.argtypes = [vp, C.POINTER(A.ht_camera), C.POINTER(A.ht_render_params),
+                                      C.POINTER(A.ht_stats)]
+    L.ht_frame_read.argtypes = [vp, A._pf32, A._pu32]
+    L.ht_frame_samples.argtypes = [vp]
+    L.ht_frame_samples.restype = C.c_int64
     _lib = L
     return L
 
@@ -170,3 +179,53 @@ class Scene:
                                    n.ctypes.data_as(A._pf32), t64.ctypes.data_as(A._pf64),
                                    n64.ctypes.data_as(A._pf64)))
         return {"t": t, "prim_id": pid, "normal": n, "t64": t64, "normal64": n64}
+
+
+class Frame:
+    """A progressive frame (ht_frame): device-resident radiance sums that sample
+    batches are added to and that can be read back after any of them."""
+
+    def __init__(self, scene: Scene, width: int, height: int):
+        self.scene, self.width, self.height = scene, width, height
+        self._h = C.c_void_p()
+        _check(load().ht_frame_create(scene.handle, width, height, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().ht_frame_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def clear(self):
+        _check(load().ht_frame_clear(self._h))
+
+    @property
+    def samples(self) -> int:
+        return int(load().ht_frame_samples(self._h))
+
+    def accumulate(self, camera, samples: int, sample_offset: Optional[int] = None, **kw) -> dict:
+        """Add `samples` paths per pixel; by default they continue where the frame stands."""
+        if sample_offset is None:
+            sample_offset = self.samples
+        p = make_params(self.width, self.height, samples, sample_offset=sample_offset, **kw)
+        st = A.ht_stats()
+        cc = camera.to_c()
+        _check(load().ht_frame_accumulate(self._h, C.byref(cc), C.byref(p), C.byref(st)))
+        return st.as_dict()
+
+    def read(self) -> dict:
+        rgb = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        packed = np.zeros((self.height, self.width), dtype=np.uint32)
+        _check(load().ht_frame_read(self._h, rgb.ctypes.data_as(A._pf32), packed.ctypes.data_as(A._pu32)))
+        return {"rgb": rgb, "packed": packed}

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import json
+import math
 import os
 import re
 from dataclasses import dataclass, field
@@ -46,10 +47,31 @@ class Perlin:
 
     @staticmethod
     def tables(seed: int) -> Tuple[np.ndarray, np.ndarray]:
-        rng = np.random.default_rng(seed)
-        v = rng.uniform(-1.0, 1.0, size=(A.HT_PERLIN_POINTS, 3))
-        v = v / np.sqrt((v * v).sum(axis=1, keepdims=True))  # Vec3.random(-1,1).unit_vector
-        perm = np.stack([rng.permutation(A.HT_PERLIN_POINTS) for _ in range(3)]).astype(np.int32)
+        """256 unit vectors and three permutations from a splitmix64 stream: the
+        same tables, bit for bit, as the C++ front-end draws for the same seed."""
+        mask = (1 << 64) - 1
+        state = [seed & mask]
+
+        def nxt() -> int:
+            state[0] = (state[0] + 0x9E3779B97F4A7C15) & mask
+            z = state[0]
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+            return z ^ (z >> 31)
+
+        n = A.HT_PERLIN_POINTS
+        v = np.empty((n, 3))
+        for i in range(n):
+            x, y, z = (-1.0 + 2.0 * ((nxt() >> 11) * 2.0 ** -53) for _ in range(3))
+            length = math.sqrt(x * x + y * y + z * z)  # Vec3.random(-1,1).unit_vector
+            v[i] = (x / length, y / length, z / length)
+        perm = np.empty((3, n), dtype=np.int32)
+        for k in range(3):
+            row = list(range(n))
+            for i in range(n - 1, 0, -1):
+                j = nxt() % (i + 1)
+                row[i], row[j] = row[j], row[i]
+            perm[k] = row
         return v, perm
 
 

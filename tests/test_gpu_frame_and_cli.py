@@ -1,0 +1,81 @@
+"""Progressive frames (ht_frame_*) and the C++ command-line front-end on a real
+MI355X.  Everything is compared bit for bit with ht_render: radiance sums are
+fixed point, so any split of the samples into batches gives the same picture."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "raytracing_amd", "host", "hiptrace-render")
+SCENES = os.path.join(ROOT, "tests", "golden", "scenes")
+
+
+@pytest.fixture(scope="module")
+def dev(ht):
+    assert ht.device_count() >= 1, "GPU tests need a HIP device; libhiptrace has no CPU path"
+    return ht
+
+
+def test_frame_batches_equal_one_render(dev, flat_scene):
+    cam, _, flat = flat_scene("scene")
+    W, H, spp = 96, 54, 24
+    with dev.Scene(flat, device=0) as s:
+        whole = s.render(cam, W, H, spp, seed=9)
+        with dev.Frame(s, W, H) as f:
+            assert f.samples == 0
+            with pytest.raises(dev.HipTraceError):  # nothing to show yet
+                f.read()
+            f.accumulate(cam, 5, seed=9)
+            part = f.read()
+            np.testing.assert_array_equal(part["packed"], s.render(cam, W, H, 5, seed=9)["packed"])
+            f.accumulate(cam, 12, seed=9)
+            st = f.accumulate(cam, 7, seed=9)
+            assert f.samples == spp and st["samples"] == 7 * W * H
+            got = f.read()
+            np.testing.assert_array_equal(got["packed"], whole["packed"])
+            np.testing.assert_array_equal(got["rgb"], whole["rgb"])
+            # a second frame, other order of the same sample ranges: same picture
+            with dev.Frame(s, W, H) as g:
+                g.accumulate(cam, 14, sample_offset=10, seed=9)
+                g.accumulate(cam, 10, sample_offset=0, seed=9)
+                np.testing.assert_array_equal(g.read()["packed"], whole["packed"])
+            f.clear()
+            assert f.samples == 0
+            f.accumulate(cam, 5, seed=9)
+            np.testing.assert_array_equal(f.read()["packed"], part["packed"])
+
+
+def test_frame_rejects_mismatched_size(dev, flat_scene):
+    cam, _, flat = flat_scene("scene")
+    with dev.Scene(flat, device=0) as s, dev.Frame(s, 32, 18) as f:
+        import ctypes as C
+        p = dev.make_params(64, 18, 1)
+        cc = cam.to_c()
+        rc = dev.load().ht_frame_accumulate(f._h, C.byref(cc), C.byref(p), None)
+        assert rc == -1 and b"frame" in dev.load().ht_last_error()
+        with pytest.raises(dev.HipTraceError):
+            dev.Frame(s, 1, 18)  # the W-1 divisor needs width >= 2
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="hiptrace-render not built")
+@pytest.mark.parametrize("scene,W,H,spp", [("scene.json", 100, 56, 70), ("perlin.json", 64, 36, 8)])
+def test_cli_writes_the_picture_ht_render_gives(dev, flat_scene, tmp_path, scene, W, H, spp):
+    """hiptrace-render = the reference's cmd mode (main.scala:106-119): C++ scene
+    reader -> ht_frame batches of 64 -> PNG.  Same library, same scene arrays, same
+    seed as the Python host, so the file holds exactly ht_render's packed pixels."""
+    from PIL import Image
+    out = str(tmp_path / "out.png")
+    r = subprocess.run([BIN, "-o", out, "--width", str(W), "--height", str(H), "--samples", str(spp),
+                        "--seed", "77", os.path.join(SCENES, scene)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert f"Rendered line [{H}/{H}]" in r.stdout and "\nTime: " in r.stdout
+    im = np.asarray(Image.open(out).convert("RGB")).astype(np.uint32)
+    got = im[..., 0] << 16 | im[..., 1] << 8 | im[..., 2]
+    cam, _, flat = flat_scene(scene[:-5])
+    with dev.Scene(flat, device=0) as s:
+        want = s.render(cam, W, H, spp, seed=77)["packed"]
+    np.testing.assert_array_equal(got, want)
