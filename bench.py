@@ -215,6 +215,14 @@ def main():
                 "lane_utilisation_in_traversal": ctr["n_active"] / max(ctr["n_steps"], 1),
             },
         }
+        if world == 1:
+            # the same frame through the host-buffer entry point (ht_render): allocation of
+            # the sums, render, resolve and the device-to-host copies of both pictures
+            t0 = time.perf_counter()
+            scene.render(cam, W, H, spp, seed=2025, batch=args.batch, device=local_rank)
+            out["host_buffer_boundary"] = {"value": total_samples / (time.perf_counter() - t0) / 1e6,
+                                           "unit": "Msamples/s",
+                                           "note": "ht_render into host memory, PCIe copies included; never the headline value"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(flat, cam, W, H)
         print(json.dumps(out), flush=True)

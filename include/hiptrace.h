@@ -143,7 +143,7 @@ typedef struct ht_render_params {
   int32_t precision;      /* HT_PRECISION_*: arithmetic type of the device path    */
   int32_t batch;          /* samples per kernel launch (cancel granularity); 0 -> default */
   uint64_t seed;          /* Philox key                                             */
-  int32_t device;         /* HIP device ordinal; -1 -> current device              */
+  int32_t device;         /* -1, or the ordinal the scene lives on (checked)       */
   int32_t collect_counters; /* 1: run the instrumented kernel and fill ht_stats.n_* */
 } ht_render_params;
 
