@@ -38,7 +38,7 @@ enum {
   HT_E_INVALID = -1,   /* bad argument / malformed scene description        */
   HT_E_NO_DEVICE = -2, /* no HIP device, or the requested one does not exist */
   HT_E_HIP = -3,       /* a HIP runtime call failed                          */
-  HT_E_TOO_LARGE = -4, /* scene does not fit the on-chip scene store         */
+  HT_E_TOO_LARGE = -4, /* scene beyond the library's limits (1 Mi primitives) */
   HT_E_CANCELLED = -5  /* ht_cancel() was observed between sample batches    */
 };
 
@@ -275,8 +275,11 @@ const char* ht_last_error(void);
  * (nodes of the library's own BVH, bytes of the on-chip scene image, depth). */
 typedef struct ht_scene_info {
   int32_t n_prims, n_nodes, bvh_depth, n_materials, n_textures;
-  int32_t lds_bytes_fp32, lds_bytes_fp64;
+  int32_t lds_bytes_fp32, lds_bytes_fp64; /* size of the scene image per precision      */
   int32_t device;
+  int32_t hbm_store_fp32, hbm_store_fp64; /* 0: the image is traversed in LDS (on-chip
+                                             store); 1: it is too large for that and is
+                                             traversed where it lies in HBM               */
 } ht_scene_info;
 int ht_scene_get_info(const ht_scene* scene, ht_scene_info* out);
 
@@ -289,7 +292,9 @@ int ht_scene_get_info(const ht_scene* scene, ht_scene_info* out);
  *   "wait_ratio_num" / "wait_ratio_den"  traversal also yields to shading when
  *                       waiting lanes / travelling lanes >= num / den
  *   "default_batch"     samples per launch when ht_render_params.batch = 0
- *   "chunk"             samples of one 8x8 tile that form one unit of the work queue */
+ *   "chunk"             samples of one 8x8 tile that form one unit of the work queue
+ *   "force_hbm_scene"   scenes created while this is 1 keep their image in HBM even if it
+ *                       would fit on chip (testing the large-scene path on small scenes) */
 int ht_set_option(const char* name, int value);
 
 #ifdef __cplusplus

@@ -122,6 +122,8 @@ class ht_scene_info(C.Structure):
         ("lds_bytes_fp32", C.c_int32),
         ("lds_bytes_fp64", C.c_int32),
         ("device", C.c_int32),
+        ("hbm_store_fp32", C.c_int32),
+        ("hbm_store_fp64", C.c_int32),
     ]
 
 

@@ -72,6 +72,7 @@ std::atomic<int> g_block_threads{0};  // 0: choose
 std::atomic<int> g_node_den{2}, g_wait_num{1000}, g_wait_den{1};
 std::atomic<int> g_default_batch{256};
 std::atomic<int> g_chunk{8};
+std::atomic<int> g_force_hbm{0};  // scenes created while set keep their image in HBM
 
 // Makes `device` current for the lifetime of the object, then restores.
 struct DeviceGuard {
@@ -139,6 +140,7 @@ int ht_set_option(const char* name, int value) {
   if (!strcmp(name, "node_den")) { g_node_den = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "wait_ratio_num")) { g_wait_num = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "wait_ratio_den")) { g_wait_den = std::max(1, value); return HT_OK; }
+  if (!strcmp(name, "force_hbm_scene")) { g_force_hbm = value ? 1 : 0; return HT_OK; }
   return fail(HT_E_INVALID, "unknown option '%s'", name);
 }
 
@@ -165,12 +167,23 @@ int ht_scene_create(const ht_scene_desc* desc, int device, ht_scene** out) {
   }
   if (device >= ndev) return fail(HT_E_NO_DEVICE, "device %d requested, %d visible", device, ndev);
 
+  hipDeviceProp_t prop;
+  {
+    hipError_t pe = hipGetDeviceProperties(&prop, device);
+    if (pe != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(HT_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(pe));
+    }
+  }
   ht_scene* s = new (std::nothrow) ht_scene;
   if (!s) return fail(HT_E_INVALID, "out of host memory");
   std::string err;
   int rc;
   try {
-    rc = build_host_scene(desc, s->hs, err);
+    BuildOptions opt;
+    opt.lds_bytes = (uint32_t)prop.sharedMemPerBlock;  // 160 KiB on gfx950
+    opt.force_hbm = g_force_hbm.load() != 0;
+    rc = build_host_scene(desc, s->hs, err, opt);
   } catch (const std::exception& e) {
     delete s;
     return fail(HT_E_INVALID, "scene flattening failed: %s", e.what());
@@ -182,22 +195,11 @@ int ht_scene_create(const ht_scene_desc* desc, int device, ht_scene** out) {
   s->device = device;
   DeviceGuard g(device);
   if (!g.ok) { delete s; return fail(HT_E_NO_DEVICE, "cannot select device %d", device); }
-  hipDeviceProp_t prop;
-  hipError_t e = hipGetDeviceProperties(&prop, device);
-  if (e != hipSuccess) { delete s; return fail(HT_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e)); }
+  hipError_t e = hipSuccess;
   s->n_cu = prop.multiProcessorCount;
-  const size_t lds_cap = prop.sharedMemPerBlock;  // 160 KiB on gfx950
   for (int t : s->hs.tex_type) {
     if (t == HT_TEX_PERLIN) s->feat |= KFEAT_PERLIN;
     if (t == HT_TEX_IMAGE) s->feat |= KFEAT_IMAGE;
-  }
-  if (lds_bytes_needed(s->hs.layout32, 256) > lds_cap) {
-    uint32_t need = lds_bytes_needed(s->hs.layout32, 256);
-    delete s;
-    return fail(HT_E_TOO_LARGE,
-                "scene image + traversal stacks need %u bytes of LDS, the device offers %zu per "
-                "workgroup; scenes beyond the on-chip store are not supported",
-                need, lds_cap);
   }
   auto upload = [&](const void* src, size_t bytes, void** dst) -> hipError_t {
     hipError_t r = hipMalloc(dst, bytes ? bytes : 16);
@@ -229,6 +231,8 @@ int ht_scene_get_info(const ht_scene* s, ht_scene_info* out) {
   out->n_textures = (int32_t)s->hs.tex_type.size();
   out->lds_bytes_fp32 = (int32_t)s->hs.layout32.total_bytes;
   out->lds_bytes_fp64 = (int32_t)s->hs.layout64.total_bytes;
+  out->hbm_store_fp32 = (int32_t)s->hs.layout32.wide;
+  out->hbm_store_fp64 = (int32_t)s->hs.layout64.wide;
   out->device = s->device;
   return HT_OK;
 }
@@ -269,7 +273,7 @@ int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_para
   for (int t = (int)max_block_threads(prec); t >= 256; t -= 128) {
     if (forced > 0 && t != forced) continue;
     const uint32_t need = lds_bytes_needed(L, (uint32_t)t);
-    int b = render_blocks_per_cu(prec, counters, s->feat, t, need);
+    int b = render_blocks_per_cu(prec, counters, s->feat, L.wide != 0u, t, need);
     b = std::min(b, g_max_blocks_per_cu.load());
     if (b * t > bpc * threads) { threads = t; bpc = b; lds = need; }
   }

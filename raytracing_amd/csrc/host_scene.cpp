@@ -211,11 +211,13 @@ template <typename R> void put_bits(Blob& bl, uint32_t off, uint32_t v) {
 }
 
 template <typename R>
-void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out) {
+void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out, bool wide) {
   out.clear();
   Blob bl{out};
   const uint32_t RS = sizeof(R);
   memset(&L, 0, sizeof L);
+  L.wide = wide ? 1u : 0u;
+  auto ref_out = [wide](uint32_t r) { return wide ? r : narrow_ref(r); };
   L.n_nodes = (uint32_t)hs.nodes.size();
   L.n_sph = (uint32_t)hs.sph.size();
   L.n_rect = (uint32_t)hs.rect.size();
@@ -235,7 +237,12 @@ void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out) 
       for (int a = 0; a < 3; ++a) bl.put<R>(o + (c * 6 + a) * RS, round_down<R>(n.lo[c][a]));
       for (int a = 0; a < 3; ++a) bl.put<R>(o + (c * 6 + 3 + a) * RS, round_up<R>(n.hi[c][a]));
     }
-    bl.put<uint32_t>(o + 12 * RS, n.child[0] | (n.child[1] << 16));
+    if (wide) {
+      bl.put<uint32_t>(o + 12 * RS, n.child[0]);
+      bl.put<uint32_t>(o + 12 * RS + 4, n.child[1]);
+    } else {
+      bl.put<uint32_t>(o + 12 * RS, narrow_ref(n.child[0]) | (narrow_ref(n.child[1]) << 16));
+    }
   }
 
   L.sph = bl.reserve((size_t)L.n_sph * 4 * RS);
@@ -318,7 +325,7 @@ void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out) 
   }
   L.n_hoist = (uint32_t)hs.hoist.size();
   L.hoist = bl.reserve((size_t)L.n_hoist * 4);
-  for (uint32_t i = 0; i < L.n_hoist; ++i) bl.put<uint32_t>(L.hoist + i * 4, hs.hoist[i]);
+  for (uint32_t i = 0; i < L.n_hoist; ++i) bl.put<uint32_t>(L.hoist + i * 4, ref_out(hs.hoist[i]));
   L.root_box = bl.reserve(8 * RS);
   for (int a = 0; a < 3; ++a) {
     bl.put<R>(L.root_box + a * RS, round_down<R>(hs.root_lo[a]));
@@ -337,7 +344,12 @@ bool texture_acyclic(const HostScene& hs, int t, int depth) {
 
 }  // namespace
 
-int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err) {
+// LDS a 256-thread workgroup needs beside the image: stacks + tile sums (kernels.hip)
+static uint32_t lds_beside_image(uint32_t depth) {
+  return ((256u * 2u * (depth > 0u ? depth : 1u) + 15u) & ~15u) + (256u / 64u) * 64u * 3u * 8u;
+}
+
+int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err, const BuildOptions& opt) {
   if (!d) { err = "scene description is NULL"; return HT_E_INVALID; }
   if (d->n_prims <= 0 || !d->prim_type || !d->prim_material || !d->prim_data) {
     err = "scene has no primitives (the reference cannot build a BVH over an empty world either)";
@@ -437,39 +449,42 @@ int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err) {
     if (k == HT_PRIM_SPHERE) {
       hs.sph.push_back(p);
     } else if (k == HT_PRIM_TRIANGLE) {
-      hs.prim_ref[p] = REF_LEAF | (KIND_TRIANGLE << REF_KIND_SHIFT) | (uint32_t)hs.tri.size();
+      hs.prim_ref[p] = WREF_LEAF | (KIND_TRIANGLE << WREF_KIND_SHIFT) | (uint32_t)hs.tri.size();
       hs.tri.push_back(p);
     } else {
       uint32_t kind = k == HT_PRIM_XYRECT ? KIND_XYRECT : (k == HT_PRIM_XZRECT ? KIND_XZRECT : KIND_YZRECT);
-      hs.prim_ref[p] = REF_LEAF | (kind << REF_KIND_SHIFT) | (uint32_t)hs.rect.size();
+      hs.prim_ref[p] = WREF_LEAF | (kind << WREF_KIND_SHIFT) | (uint32_t)hs.rect.size();
       hs.rect.push_back(p);
     }
   }
-  if (hs.sph.size() > MAX_PER_KIND || hs.rect.size() > MAX_PER_KIND || hs.tri.size() > MAX_PER_KIND) {
-    err = "more than 4096 primitives of one kind: beyond the on-chip scene store";
-    return HT_E_TOO_LARGE;
-  }
+  const bool fits_refs16 =
+      hs.sph.size() <= MAX_PER_KIND && hs.rect.size() <= MAX_PER_KIND && hs.tri.size() <= MAX_PER_KIND;
   // A sphere that dwarfs everything else (a "ground" sphere) is intersected in
   // the expanded form |o|^2 - 2 o.c + (|c|^2 - r^2): its error scales with the
   // distance of the ray origin from the WORLD origin, not with r^2.
   hs.sph_big.assign(hs.sph.size(), 0);
+  // reach of every primitive from the world origin: the largest and the runner-up
+  // give "everything else in the scene" for any one primitive in O(1)
+  double reach1 = 0, reach2 = 0;
+  int reach1_at = -1;
+  for (int q = 0; q < n; ++q) {
+    const Box& b = boxes[q];
+    double m = 0;
+    for (int a = 0; a < 3; ++a) { double v = std::max(fabs(b.lo[a]), fabs(b.hi[a])); m += v * v; }
+    m = sqrt(m);
+    if (m > reach1) { reach2 = reach1; reach1 = m; reach1_at = q; }
+    else if (m > reach2) reach2 = m;
+  }
   for (size_t i = 0; i < hs.sph.size(); ++i) {
     int p = hs.sph[i];
     const double* pd = &hs.prim_data[(size_t)p * HT_PRIM_STRIDE];
     double r = fabs(pd[3]);
-    double E = 0;  // radius about the world origin of everything else in the scene
-    for (int q = 0; q < n; ++q) {
-      if (q == p) continue;
-      const Box& b = boxes[q];
-      double m = 0;
-      for (int a = 0; a < 3; ++a) { double v = std::max(fabs(b.lo[a]), fabs(b.hi[a])); m += v * v; }
-      E = std::max(E, sqrt(m));
-    }
+    const double E = (p == reach1_at) ? reach2 : reach1;  // radius about the world origin of everything else
     double cl = sqrt(pd[0] * pd[0] + pd[1] * pd[1] + pd[2] * pd[2]);
     double K = fabs(cl * cl - r * r);
     bool big = 4.0 * (E * E + 2.0 * E * cl + K) < r * r;
     hs.sph_big[i] = big ? 1 : 0;
-    hs.prim_ref[p] = REF_LEAF | ((big ? KIND_BIG_SPHERE : KIND_SPHERE) << REF_KIND_SHIFT) | (uint32_t)i;
+    hs.prim_ref[p] = WREF_LEAF | ((big ? KIND_BIG_SPHERE : KIND_SPHERE) << WREF_KIND_SHIFT) | (uint32_t)i;
   }
 
   // ---- hoisted primitives + hierarchy ---------------------------------------------
@@ -535,17 +550,32 @@ int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err) {
   } else if (nb > 1) {
     Builder b{hs, items};
     Box rb;
-    b.build(0, nb, STACK_MAX_DEPTH, 0, rb);
+    // a hierarchy that can live on chip gets the on-chip depth bound; a larger one
+    // gets the deeper bound of the HBM store
+    const bool small = fits_refs16 && (uint32_t)(nb - 1) <= MAX_NODES && !opt.force_hbm;
+    b.build(0, nb, small ? STACK_MAX_DEPTH : WIDE_STACK_MAX_DEPTH, 0, rb);
     hs.depth = b.max_level;
   }
   for (int a = 0; a < 3; ++a) {
     hs.root_lo[a] = nb ? root.lo[a] : 0.0;
     hs.root_hi[a] = nb ? root.hi[a] : 0.0;
   }
-  if (hs.nodes.size() > MAX_NODES) { err = "too many BVH nodes"; return HT_E_TOO_LARGE; }
-
-  write_blob<float>(hs, hs.layout32, hs.blob32);
-  write_blob<double>(hs, hs.layout64, hs.blob64);
+  if (hs.sph.size() > WIDE_MAX_PER_KIND || hs.rect.size() > WIDE_MAX_PER_KIND || hs.tri.size() > WIDE_MAX_PER_KIND) {
+    err = "too many primitives of one kind";
+    return HT_E_TOO_LARGE;
+  }
+  const bool chip_ok = fits_refs16 && hs.nodes.size() <= MAX_NODES && hs.depth <= STACK_MAX_DEPTH && !opt.force_hbm;
+  const uint32_t beside = lds_beside_image((uint32_t)hs.depth);
+  write_blob<float>(hs, hs.layout32, hs.blob32, !chip_ok);
+  if (chip_ok && (uint64_t)hs.layout32.total_bytes + beside > opt.lds_bytes)
+    write_blob<float>(hs, hs.layout32, hs.blob32, true);
+  write_blob<double>(hs, hs.layout64, hs.blob64, !chip_ok);
+  if (chip_ok && (uint64_t)hs.layout64.total_bytes + beside > opt.lds_bytes)
+    write_blob<double>(hs, hs.layout64, hs.blob64, true);
+  if (hs.blob32.size() > 0xFFFFFFF0ull || hs.blob64.size() > 0xFFFFFFF0ull) {
+    err = "scene image exceeds 4 GiB";
+    return HT_E_TOO_LARGE;
+  }
   return HT_OK;
 }
 

@@ -13,7 +13,7 @@ namespace ht {
 
 struct BvhNode {
   double lo[2][3], hi[2][3];  // boxes of the two children
-  uint32_t child[2];          // 16-bit references (scene_layout.h)
+  uint32_t child[2];          // 32-bit references (scene_layout.h); narrowed when a blob is written
 };
 
 struct HostScene {
@@ -34,7 +34,7 @@ struct HostScene {
   // per-kind arrays: primitive ids in kind-local order
   std::vector<int32_t> sph, rect, tri;
   std::vector<uint8_t> sph_big;     // KIND_BIG_SPHERE flag per entry of sph
-  std::vector<uint32_t> prim_ref;   // leaf reference of every primitive
+  std::vector<uint32_t> prim_ref;   // leaf reference (32-bit form) of every primitive
 
   std::vector<uint32_t> hoist;      // leaf references every ray tests linearly (not in the BVH)
   std::vector<BvhNode> nodes;       // hierarchy over the remaining primitives (may be empty)
@@ -45,8 +45,17 @@ struct HostScene {
   std::vector<uint8_t> blob32, blob64;
 };
 
+struct BuildOptions {
+  uint32_t lds_bytes = 160u * 1024u;  // LDS one workgroup may use on the target device
+  bool force_hbm = false;             // put the scene image in the HBM store even if it fits on chip
+};
+
 // Validates `desc` and fills `out`; returns HT_OK or an error code with `err` set.
-int build_host_scene(const ht_scene_desc* desc, HostScene& out, std::string& err);
+// Each precision's image goes to the on-chip store if it fits there (reference
+// limits, LDS budget next to the stacks of a 256-thread workgroup), else to the
+// HBM store (layoutNN.wide).
+int build_host_scene(const ht_scene_desc* desc, HostScene& out, std::string& err,
+                     const BuildOptions& opt = BuildOptions());
 
 // Camera.scala:5-17 in fp64: origin, lower_left_corner, horizontal, vertical, u, v, w, lens_radius
 struct CameraBasis {

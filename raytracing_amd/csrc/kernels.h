@@ -16,7 +16,7 @@ struct CamDev {
 };
 
 struct RenderArgs {
-  const uint8_t* blob;     // scene image in global memory (copied to LDS per workgroup)
+  const uint8_t* blob;     // scene image in global memory (copied to LDS per workgroup unless L.wide)
   SceneLayout L;
   const uint32_t* texels;  // image texels, 0x00RRGGBB
   long long* accum;        // [H*W*3] radiance sums, signed 32.32 fixed point, row 0 = bottom
@@ -65,8 +65,10 @@ constexpr uint32_t KFEAT_PERLIN = 1u, KFEAT_IMAGE = 2u;
 
 // Number of workgroups of `threads` threads per CU the device can hold for this
 // kernel variant and LDS size (0: does not fit).
-int render_blocks_per_cu(int precision, bool counters, uint32_t feat, int threads, uint32_t lds_bytes);
+int render_blocks_per_cu(int precision, bool counters, uint32_t feat, bool wide, int threads,
+                         uint32_t lds_bytes);
 
+// a.L.wide / the layout's store selects the kernel variant
 hipError_t launch_render(int precision, bool counters, uint32_t feat, const RenderArgs& a, const void* cam,
                          int grid_blocks, int threads, uint32_t lds_bytes, hipStream_t stream);
 hipError_t launch_first_hit(int precision, const FirstHitArgs& a, const void* cam, int threads,

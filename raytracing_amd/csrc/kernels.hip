@@ -7,7 +7,9 @@
 // Execution model
 //  * a workgroup copies the scene image (scene_layout.h) into LDS once; every
 //    scene of the reference fits (<= ~60 KB), so traversal never touches HBM.
-//    Image texels are the only global reads.
+//    Image texels are the only global reads.  Scenes beyond the LDS store (large
+//    meshes) run the WIDE variants of the same kernels, which read the image where
+//    it lies in global memory and keep only the stacks and tile sums in LDS.
 //  * each wave pulls 8x8-pixel tiles from a global counter; lane = pixel.
 //  * lanes are small state machines (TRAV / WAIT / DEAD / DONE).  The wave runs
 //    traversal steps while enough lanes are traversing; when `wait_threshold`
@@ -132,34 +134,46 @@ template <typename R> __device__ __forceinline__ R u01(uint32_t x) {
 // scene image accessors (LDS)
 // ---------------------------------------------------------------------------
 struct Scene {
-  const uint8_t* base;  // LDS
+  const uint8_t* base;  // LDS (on-chip store) or global memory (HBM store)
   SceneLayout L;
 };
 
-template <typename R>
-__device__ __forceinline__ void load_node(const Scene& sc, uint32_t idx, R b[12], uint32_t& cc);
-
-template <>
-__device__ __forceinline__ void load_node<float>(const Scene& sc, uint32_t idx, float b[12], uint32_t& cc) {
-  const uint8_t* p = sc.base + sc.L.nodes + idx * 64u;
+// child references of a node: packed in one word (on-chip store) or two words (HBM store)
+template <bool WIDE>
+__device__ __forceinline__ void load_children(const uint8_t* p, uint32_t& c0, uint32_t& c1) {
+  if constexpr (WIDE) {
+    const uint2 cc = *(const uint2*)p;
+    c0 = cc.x;
+    c1 = cc.y;
+  } else {
+    const uint32_t cc = *(const uint32_t*)p;
+    c0 = cc & 0xFFFFu;
+    c1 = cc >> 16;
+  }
+}
+template <bool WIDE>
+__device__ __forceinline__ void load_node(const Scene& sc, uint32_t idx, float b[12], uint32_t& c0,
+                                          uint32_t& c1) {
+  const uint8_t* p = sc.base + sc.L.nodes + (size_t)idx * 64u;
   float4 a0 = *(const float4*)(p);
   float4 a1 = *(const float4*)(p + 16);
   float4 a2 = *(const float4*)(p + 32);
-  cc = *(const uint32_t*)(p + 48);
+  load_children<WIDE>(p + 48, c0, c1);
   b[0] = a0.x; b[1] = a0.y; b[2] = a0.z; b[3] = a0.w;
   b[4] = a1.x; b[5] = a1.y; b[6] = a1.z; b[7] = a1.w;
   b[8] = a2.x; b[9] = a2.y; b[10] = a2.z; b[11] = a2.w;
 }
-template <>
-__device__ __forceinline__ void load_node<double>(const Scene& sc, uint32_t idx, double b[12], uint32_t& cc) {
-  const uint8_t* p = sc.base + sc.L.nodes + idx * 112u;
+template <bool WIDE>
+__device__ __forceinline__ void load_node(const Scene& sc, uint32_t idx, double b[12], uint32_t& c0,
+                                          uint32_t& c1) {
+  const uint8_t* p = sc.base + sc.L.nodes + (size_t)idx * 112u;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
     double2 v = *(const double2*)(p + 16 * i);
     b[2 * i] = v.x;
     b[2 * i + 1] = v.y;
   }
-  cc = *(const uint32_t*)(p + 96);
+  load_children<WIDE>(p + 96, c0, c1);
 }
 
 template <typename R>
@@ -190,16 +204,16 @@ __device__ __forceinline__ void ray_setup(Ray<R>& r) {
 template <typename R>
 struct Trav {
   uint32_t cur;       // reference being processed; REF_EMPTY when the ray is finished
-  uint32_t sp;        // stack entries in use
+  uint32_t sp;        // stack elements in use: level * blockDim.x
   uint32_t best_ref;  // REF_EMPTY = no hit yet
   R best_t;
 };
 
-template <typename R>
+template <typename R, bool WIDE>
 __device__ __forceinline__ void trav_begin(Trav<R>& tv) {
   tv.cur = 0;  // root is inner node 0
   tv.sp = 0;
-  tv.best_ref = REF_EMPTY;
+  tv.best_ref = RefT<WIDE>::EMPTY;
   tv.best_t = M<R>::inf();
 }
 
@@ -316,10 +330,10 @@ __device__ __forceinline__ void tri_solve(const TriGeom<R>& g, const Ray<R>& ray
 }
 
 // One primitive against the ray; a closer accepted hit replaces tv.best_*.
-template <typename R, bool CNT>
+template <typename R, bool CNT, bool WIDE>
 __device__ __forceinline__ void prim_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t ref,
                                           R t_min, Cnt& cnt) {
-  const uint32_t kind = (ref >> REF_KIND_SHIFT) & 7u, idx = ref & REF_INDEX_MASK;
+  const uint32_t kind = (ref >> RefT<WIDE>::KIND_SHIFT) & 7u, idx = ref & RefT<WIDE>::INDEX_MASK;
   if (kind == KIND_SPHERE || kind == KIND_BIG_SPHERE) {
     if (CNT) cnt.v[CTR_SPHERE]++;
     SphereSolve<R> ss;
@@ -356,52 +370,51 @@ __device__ __forceinline__ void prim_test(const Scene& sc, const Ray<R>& ray, Tr
 // carry no entry distance: with near-child-first descent, culling popped entries
 // against the closest hit saved only ~2.5 % of the box tests on the reference's
 // scenes, less than the LDS it costs.)
-template <typename R>
-__device__ __forceinline__ uint32_t trav_pop(Trav<R>& tv, const uint16_t* stack_lane) {
-  if (tv.sp == 0u) return REF_EMPTY;
-  tv.sp--;
-  return (uint32_t)stack_lane[tv.sp * blockDim.x];  // stack layout is [level][thread]
+template <typename R, bool WIDE>
+__device__ __forceinline__ uint32_t trav_pop(Trav<R>& tv, const typename RefT<WIDE>::stack_t* stack_lane) {
+  if (tv.sp == 0u) return RefT<WIDE>::EMPTY;
+  tv.sp -= blockDim.x;  // stack layout is [level][thread]; sp counts elements, not levels
+  return (uint32_t)stack_lane[tv.sp];
 }
 
 // Inner node: slab-test both children, descend into the nearer one that is hit
 // and push the other, or pop when neither is.
-template <typename R, bool CNT>
+template <typename R, bool CNT, bool WIDE>
 __device__ __forceinline__ void node_step(const Scene& sc, const Ray<R>& ray, Trav<R>& tv,
-                                          uint16_t* stack_lane, R t_min, Cnt& cnt) {
+                                          typename RefT<WIDE>::stack_t* stack_lane, R t_min, Cnt& cnt) {
   const uint32_t BT = blockDim.x;
   R b[12];
-  uint32_t cc;
-  load_node<R>(sc, tv.cur, b, cc);
+  uint32_t c0, c1;
+  load_node<WIDE>(sc, tv.cur, b, c0, c1);
   R tn0, tn1;
   const bool h0 = slab<R>(ray, b[0], b[1], b[2], b[3], b[4], b[5], t_min, tv.best_t, tn0);
   const bool h1 = slab<R>(ray, b[6], b[7], b[8], b[9], b[10], b[11], t_min, tv.best_t, tn1);
-  const uint32_t c0 = cc & 0xFFFFu, c1 = cc >> 16;
   if (CNT) cnt.v[CTR_BOX] += 2;
   if (h0 && h1) {
     const bool swp = tn1 < tn0;
     const uint32_t nearc = swp ? c1 : c0, farc = swp ? c0 : c1;
-    stack_lane[tv.sp * BT] = (uint16_t)farc;
-    tv.sp++;
+    stack_lane[tv.sp] = (typename RefT<WIDE>::stack_t)farc;
+    tv.sp += BT;
     tv.cur = nearc;
   } else if (h0 || h1) {
     tv.cur = h0 ? c0 : c1;
   } else {
-    tv.cur = trav_pop<R>(tv, stack_lane);
+    tv.cur = trav_pop<R, WIDE>(tv, stack_lane);
   }
 }
 
 // Start of a ray: the hoisted primitives (the same primitive for every lane, so
 // the wave runs one code path), then the bounds of the hierarchy.
-template <typename R, bool CNT>
+template <typename R, bool CNT, bool WIDE>
 __device__ __forceinline__ void ray_start(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, R t_min,
                                           Cnt& cnt) {
-  trav_begin<R>(tv);
+  trav_begin<R, WIDE>(tv);
   const uint32_t* hl = (const uint32_t*)(sc.base + sc.L.hoist);
   for (uint32_t i = 0; i < sc.L.n_hoist; ++i) {
     const uint32_t ref = __builtin_amdgcn_readfirstlane(hl[i]);
-    prim_test<R, CNT>(sc, ray, tv, ref, t_min, cnt);
+    prim_test<R, CNT, WIDE>(sc, ray, tv, ref, t_min, cnt);
   }
-  tv.cur = REF_EMPTY;
+  tv.cur = RefT<WIDE>::EMPTY;
   if (sc.L.n_nodes != 0u) {
     const R* rb = (const R*)(sc.base + sc.L.root_box);
     R tn;
@@ -411,17 +424,17 @@ __device__ __forceinline__ void ray_start(const Scene& sc, const Ray<R>& ray, Tr
 }
 
 // The whole closest-hit query of one lane (first-hit kernel).
-template <typename R>
+template <typename R, bool WIDE>
 __device__ __forceinline__ void trace_closest(const Scene& sc, const Ray<R>& ray, Trav<R>& tv,
-                                              uint16_t* stack_lane, R t_min) {
+                                              typename RefT<WIDE>::stack_t* stack_lane, R t_min) {
   Cnt cnt;
-  ray_start<R, false>(sc, ray, tv, t_min, cnt);
-  while (tv.cur != REF_EMPTY) {
-    if (!(tv.cur & REF_LEAF)) {
-      node_step<R, false>(sc, ray, tv, stack_lane, t_min, cnt);
+  ray_start<R, false, WIDE>(sc, ray, tv, t_min, cnt);
+  while (tv.cur != RefT<WIDE>::EMPTY) {
+    if (!(tv.cur & RefT<WIDE>::LEAF)) {
+      node_step<R, false, WIDE>(sc, ray, tv, stack_lane, t_min, cnt);
     } else {
-      prim_test<R, false>(sc, ray, tv, tv.cur, t_min, cnt);
-      tv.cur = trav_pop<R>(tv, stack_lane);
+      prim_test<R, false, WIDE>(sc, ray, tv, tv.cur, t_min, cnt);
+      tv.cur = trav_pop<R, WIDE>(tv, stack_lane);
     }
   }
 }
@@ -436,12 +449,12 @@ struct HitGeom {
   V3<R> n_out;  // outward_normal as the primitive reports it
 };
 
-template <typename R>
+template <typename R, bool WIDE>
 __device__ __forceinline__ HitGeom<R> hit_geometry(const Scene& sc, const Ray<R>& ray, R t,
                                                    uint32_t ref) {
   HitGeom<R> h;
-  h.kind = (ref >> REF_KIND_SHIFT) & 7u;
-  h.idx = ref & REF_INDEX_MASK;
+  h.kind = (ref >> RefT<WIDE>::KIND_SHIFT) & 7u;
+  h.idx = ref & RefT<WIDE>::INDEX_MASK;
   h.p = ray.o + t * ray.d;
   if (h.kind == KIND_SPHERE || h.kind == KIND_BIG_SPHERE) {
     // outward normal (p - center)/radius (Hittable.scala:44).  For an ordinary
@@ -650,11 +663,11 @@ struct Surface {
 // Camera.scala:29-33): geometry, material record, texture.  Emission deposits and
 // ends the path (returns false); otherwise T is multiplied by the attenuation and
 // `sf` describes the surface for scatter_direction().
-template <typename R, bool CNT, uint32_t FEAT>
+template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
 __device__ __forceinline__ bool shade_surface(const Scene& sc, const RenderArgs& A, const Ray<R>& ray,
                                               const Trav<R>& tv, V3<R>& T, const Sink& sink,
                                               Surface<R>& sf, Cnt& cnt) {
-  HitGeom<R> h = hit_geometry<R>(sc, ray, tv.best_t, tv.best_ref);
+  HitGeom<R> h = hit_geometry<R, WIDE>(sc, ray, tv.best_t, tv.best_ref);
   typename M<R>::R4 m = load_r4<R>(sc, sc.L.mat, h.meta >> META_MAT_SHIFT);
   const uint32_t m0 = M<R>::bits_lo(m.x);
   const uint32_t tex = m0 >> 4;
@@ -750,11 +763,12 @@ __device__ __forceinline__ void copy_scene_to_lds(uint8_t* lds, const uint8_t* b
 
 enum : uint32_t { ST_TRAV = 0, ST_WAIT = 1, ST_DEAD = 2, ST_DONE = 3 };
 
-// LDS of a render workgroup: [scene image][traversal stacks][per-wave tile sums]
-// (a lane pushes at most one entry per level of inner nodes above it)
-__host__ __device__ inline uint32_t stack_bytes(uint32_t threads, uint32_t depth) {
-  return (threads * 2u * (depth > 0u ? depth : 1u) + 15u) & ~15u;
+// LDS of a render workgroup: [scene image (on-chip store only)][traversal stacks]
+// [per-wave tile sums]  (a lane pushes at most one entry per level of inner nodes above it)
+__host__ __device__ inline uint32_t stack_bytes(uint32_t threads, uint32_t depth, uint32_t wide) {
+  return (threads * (wide ? 4u : 2u) * (depth > 0u ? depth : 1u) + 15u) & ~15u;
 }
+__host__ __device__ inline uint32_t image_bytes_in_lds(const SceneLayout& L) { return L.wide ? 0u : L.total_bytes; }
 constexpr uint32_t TILE_PIXELS = TILE_W * TILE_H;       // 64 = one wave
 constexpr uint32_t TILE_ACC_BYTES = TILE_PIXELS * 3u * 8u;
 
@@ -764,17 +778,25 @@ constexpr uint32_t TILE_ACC_BYTES = TILE_PIXELS * 3u * 8u;
 // dead lanes claim the next (pixel, sample) items of the current unit, and when
 // the unit runs out the wave moves on to the next one at once while the
 // stragglers of the old unit are still in flight.
-template <typename R, bool CNT, uint32_t FEAT>
+template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
 __global__ void __launch_bounds__(M<R>::BT) render_kernel(RenderArgs A, CamDev<R> cam) {
   extern __shared__ __align__(16) uint8_t lds[];
+  typedef RefT<WIDE> RF;
+  typedef typename RF::stack_t stack_t;
   const uint32_t BT = blockDim.x;  // <= M<R>::BT, a multiple of 64
-  copy_scene_to_lds(lds, A.blob, A.L.total_bytes, BT);
   Scene sc;
-  sc.base = lds;
   sc.L = A.L;
-  uint16_t* stack_lane = (uint16_t*)(lds + A.L.total_bytes) + threadIdx.x;
+  uint32_t lds_image = 0;
+  if constexpr (WIDE) {
+    sc.base = A.blob;
+  } else {
+    copy_scene_to_lds(lds, A.blob, A.L.total_bytes, BT);
+    sc.base = lds;
+    lds_image = A.L.total_bytes;
+  }
+  stack_t* stack_lane = (stack_t*)(lds + lds_image) + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63u;
-  unsigned long long* tile_acc = (unsigned long long*)(lds + A.L.total_bytes + stack_bytes(BT, A.L.depth) +
+  unsigned long long* tile_acc = (unsigned long long*)(lds + lds_image + stack_bytes(BT, A.L.depth, WIDE ? 1u : 0u) +
                                                        (threadIdx.x >> 6) * TILE_ACC_BYTES);
   unsigned long long* frame = (unsigned long long*)A.accum;
   const uint32_t tiles_x = (uint32_t)(A.W + TILE_W - 1) / TILE_W;
@@ -811,7 +833,7 @@ __global__ void __launch_bounds__(M<R>::BT) render_kernel(RenderArgs A, CamDev<R
   uint32_t my_epoch = 0, pix = 0, pixel = 0, sample = 0, bounce = 0;
   ray.o = ray.d = ray.inv = mk<R>((R)0, (R)0, (R)0);
   ray.a = ray.inv_a = ray.oo = (R)0;
-  trav_begin<R>(tv);
+  trav_begin<R, WIDE>(tv);
 
   // adds the wave's tile sums to the frame and clears them
   auto flush_tile = [&]() {
@@ -848,10 +870,10 @@ __global__ void __launch_bounds__(M<R>::BT) render_kernel(RenderArgs A, CamDev<R
       sink.global = frame + (size_t)pixel * 3u;
       sink.current = my_epoch == epoch;
       state = ST_DEAD;
-      if (tv.best_ref == REF_EMPTY) {
+      if (tv.best_ref == RF::EMPTY) {
         deposit<R>(sink, T * bg);  // case None => background (Camera.scala:34)
         if (CNT) cnt.v[CTR_MISS]++;
-      } else if (shade_surface<R, CNT, FEAT>(sc, A, ray, tv, T, sink, sf, cnt)) {
+      } else if (shade_surface<R, CNT, FEAT, WIDE>(sc, A, ray, tv, T, sink, sf, cnt)) {
         // depth exhausted: the scattered ray's ray_color returns 0 (Camera.scala:27),
         // so the path contributes nothing more
         scatter = bounce < (uint32_t)A.max_depth;
@@ -926,8 +948,8 @@ __global__ void __launch_bounds__(M<R>::BT) render_kernel(RenderArgs A, CamDev<R
       if (go) {
         bounce++;
         ray_setup<R>(ray);
-        ray_start<R, CNT>(sc, ray, tv, t_min, cnt);
-        state = (tv.cur == REF_EMPTY) ? ST_WAIT : ST_TRAV;
+        ray_start<R, CNT, WIDE>(sc, ray, tv, t_min, cnt);
+        state = (tv.cur == RF::EMPTY) ? ST_WAIT : ST_TRAV;
         if (CNT) cnt.v[CTR_RAYS]++;
       }  // else: absorbed, the lane stays DEAD and claims new work next round
     }
@@ -944,24 +966,24 @@ __global__ void __launch_bounds__(M<R>::BT) render_kernel(RenderArgs A, CamDev<R
     //         step for the lanes that reached a primitive; until enough rays are done ----
     while (__ballot(state == ST_TRAV) != 0ull) {
       for (;;) {
-        const bool inner = state == ST_TRAV && !(tv.cur & REF_LEAF);
+        const bool inner = state == ST_TRAV && !(tv.cur & RF::LEAF);
         const uint64_t mi = __ballot(inner);
         const uint64_t mt = __ballot(state == ST_TRAV);
         // leaves wait while at least a third of the travelling lanes still descend
         if (mi == 0ull || A.node_den * __popcll(mi) < __popcll(mt)) break;
         if (inner) {
-          node_step<R, CNT>(sc, ray, tv, stack_lane, t_min, cnt);
-          if (tv.cur == REF_EMPTY) state = ST_WAIT;
+          node_step<R, CNT, WIDE>(sc, ray, tv, stack_lane, t_min, cnt);
+          if (tv.cur == RF::EMPTY) state = ST_WAIT;
           if (CNT) cnt.v[CTR_ACTIVE]++;
         }
         if (CNT) cnt.v[CTR_STEPS]++;
       }
-      const bool leaf = state == ST_TRAV && (tv.cur & REF_LEAF);
+      const bool leaf = state == ST_TRAV && (tv.cur & RF::LEAF);
       if (__ballot(leaf) != 0ull) {
         if (leaf) {
-          prim_test<R, CNT>(sc, ray, tv, tv.cur, t_min, cnt);
-          tv.cur = trav_pop<R>(tv, stack_lane);
-          if (tv.cur == REF_EMPTY) state = ST_WAIT;
+          prim_test<R, CNT, WIDE>(sc, ray, tv, tv.cur, t_min, cnt);
+          tv.cur = trav_pop<R, WIDE>(tv, stack_lane);
+          if (tv.cur == RF::EMPTY) state = ST_WAIT;
           if (CNT) cnt.v[CTR_ACTIVE]++;
         }
         if (CNT) cnt.v[CTR_STEPS]++;
@@ -995,15 +1017,22 @@ __global__ void __launch_bounds__(M<R>::BT) render_kernel(RenderArgs A, CamDev<R
 }
 
 // world.hit(camera ray through the pixel centre, 0.001, +inf) for every pixel.
-template <typename R>
+template <typename R, bool WIDE>
 __global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, CamDev<R> cam) {
   extern __shared__ __align__(16) uint8_t lds[];
+  typedef typename RefT<WIDE>::stack_t stack_t;
   const uint32_t BT = blockDim.x;
-  copy_scene_to_lds(lds, A.blob, A.L.total_bytes, BT);
   Scene sc;
-  sc.base = lds;
   sc.L = A.L;
-  uint16_t* stack_lane = (uint16_t*)(lds + A.L.total_bytes) + threadIdx.x;
+  uint32_t lds_image = 0;
+  if constexpr (WIDE) {
+    sc.base = A.blob;
+  } else {
+    copy_scene_to_lds(lds, A.blob, A.L.total_bytes, BT);
+    sc.base = lds;
+    lds_image = A.L.total_bytes;
+  }
+  stack_t* stack_lane = (stack_t*)(lds + lds_image) + threadIdx.x;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t tiles_x = (uint32_t)(A.W + TILE_W - 1) / TILE_W;
   const uint32_t tiles_y = (uint32_t)(A.H + TILE_H - 1) / TILE_H;
@@ -1023,16 +1052,16 @@ __global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, Cam
   camera_ray<R>(ra, cam, ray, px, py, no_rnd);  // jitter off: pixel centre, lens closed
   ray_setup<R>(ray);
   Trav<R> tv;
-  trace_closest<R>(sc, ray, tv, stack_lane, (R)0.001);
+  trace_closest<R, WIDE>(sc, ray, tv, stack_lane, (R)0.001);
 
   R* t_out = (R*)A.t;
   R* n_out = (R*)A.normal;
-  if (tv.best_ref == REF_EMPTY) {
+  if (tv.best_ref == RefT<WIDE>::EMPTY) {
     t_out[pixel] = M<R>::inf();
     A.prim[pixel] = -1;
     n_out[pixel * 3u] = n_out[pixel * 3u + 1u] = n_out[pixel * 3u + 2u] = (R)0;
   } else {
-    HitGeom<R> h = hit_geometry<R>(sc, ray, tv.best_t, tv.best_ref);
+    HitGeom<R> h = hit_geometry<R, WIDE>(sc, ray, tv.best_t, tv.best_ref);
     const bool front = dot(ray.d, h.n_out) < (R)0;
     const V3<R> n = front ? h.n_out : -h.n_out;
     t_out[pixel] = tv.best_t;
@@ -1068,7 +1097,7 @@ __global__ void resolve_kernel(const long long* __restrict__ accum, int32_t W, i
 // launchers
 // ---------------------------------------------------------------------------
 uint32_t lds_bytes_needed(const SceneLayout& L, uint32_t threads) {
-  return L.total_bytes + stack_bytes(threads, L.depth) + (threads / 64u) * TILE_ACC_BYTES;
+  return image_bytes_in_lds(L) + stack_bytes(threads, L.depth, L.wide) + (threads / 64u) * TILE_ACC_BYTES;
 }
 uint32_t max_block_threads(int precision) { return precision == 0 ? M<float>::BT : M<double>::BT; }
 
@@ -1081,25 +1110,24 @@ static hipError_t allow_big_lds(K kernel, uint32_t lds_bytes) {
 namespace {
 typedef void (*RenderKernel32)(RenderArgs, CamDev<float>);
 typedef void (*RenderKernel64)(RenderArgs, CamDev<double>);
-// [counters][feat]
-const RenderKernel32 k32[2][4] = {
-    {render_kernel<float, false, 0>, render_kernel<float, false, 1>, render_kernel<float, false, 2>,
-     render_kernel<float, false, 3>},
-    {render_kernel<float, true, 0>, render_kernel<float, true, 1>, render_kernel<float, true, 2>,
-     render_kernel<float, true, 3>}};
-const RenderKernel64 k64[2][4] = {
-    {render_kernel<double, false, 0>, render_kernel<double, false, 1>, render_kernel<double, false, 2>,
-     render_kernel<double, false, 3>},
-    {render_kernel<double, true, 0>, render_kernel<double, true, 1>, render_kernel<double, true, 2>,
-     render_kernel<double, true, 3>}};
-const void* render_kernel_ptr(int precision, bool counters, uint32_t feat) {
-  return precision == 0 ? reinterpret_cast<const void*>(k32[counters ? 1 : 0][feat & 3u])
-                        : reinterpret_cast<const void*>(k64[counters ? 1 : 0][feat & 3u]);
+#define HT_FEAT_ROW(R, CNT, WIDE)                                                              \
+  {render_kernel<R, CNT, 0, WIDE>, render_kernel<R, CNT, 1, WIDE>, render_kernel<R, CNT, 2, WIDE>, \
+   render_kernel<R, CNT, 3, WIDE>}
+// [store][counters][feat]
+const RenderKernel32 k32[2][2][4] = {{HT_FEAT_ROW(float, false, false), HT_FEAT_ROW(float, true, false)},
+                                     {HT_FEAT_ROW(float, false, true), HT_FEAT_ROW(float, true, true)}};
+const RenderKernel64 k64[2][2][4] = {{HT_FEAT_ROW(double, false, false), HT_FEAT_ROW(double, true, false)},
+                                     {HT_FEAT_ROW(double, false, true), HT_FEAT_ROW(double, true, true)}};
+#undef HT_FEAT_ROW
+const void* render_kernel_ptr(int precision, bool counters, uint32_t feat, bool wide) {
+  return precision == 0 ? reinterpret_cast<const void*>(k32[wide ? 1 : 0][counters ? 1 : 0][feat & 3u])
+                        : reinterpret_cast<const void*>(k64[wide ? 1 : 0][counters ? 1 : 0][feat & 3u]);
 }
 }  // namespace
 
-int render_blocks_per_cu(int precision, bool counters, uint32_t feat, int threads, uint32_t lds_bytes) {
-  const void* k = render_kernel_ptr(precision, counters, feat);
+int render_blocks_per_cu(int precision, bool counters, uint32_t feat, bool wide, int threads,
+                         uint32_t lds_bytes) {
+  const void* k = render_kernel_ptr(precision, counters, feat, wide);
   if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
@@ -1114,13 +1142,24 @@ int render_blocks_per_cu(int precision, bool counters, uint32_t feat, int thread
 
 hipError_t launch_render(int precision, bool counters, uint32_t feat, const RenderArgs& a, const void* cam,
                          int grid_blocks, int threads, uint32_t lds_bytes, hipStream_t stream) {
+  const int w = a.L.wide ? 1 : 0;
   if (precision == 0) {
-    hipLaunchKernelGGL(k32[counters ? 1 : 0][feat & 3u], dim3(grid_blocks), dim3(threads), lds_bytes, stream,
+    hipLaunchKernelGGL(k32[w][counters ? 1 : 0][feat & 3u], dim3(grid_blocks), dim3(threads), lds_bytes, stream,
                        a, *static_cast<const CamDev<float>*>(cam));
   } else {
-    hipLaunchKernelGGL(k64[counters ? 1 : 0][feat & 3u], dim3(grid_blocks), dim3(threads), lds_bytes, stream,
+    hipLaunchKernelGGL(k64[w][counters ? 1 : 0][feat & 3u], dim3(grid_blocks), dim3(threads), lds_bytes, stream,
                        a, *static_cast<const CamDev<double>*>(cam));
   }
+  return hipGetLastError();
+}
+
+template <typename R, bool WIDE>
+static hipError_t launch_first_hit_t(const FirstHitArgs& a, const void* cam, uint32_t blocks, int threads,
+                                     uint32_t lds_bytes, hipStream_t stream) {
+  hipError_t e = allow_big_lds(first_hit_kernel<R, WIDE>, lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((first_hit_kernel<R, WIDE>), dim3(blocks), dim3(threads), lds_bytes, stream, a,
+                     *static_cast<const CamDev<R>*>(cam));
   return hipGetLastError();
 }
 
@@ -1128,18 +1167,12 @@ hipError_t launch_first_hit(int precision, const FirstHitArgs& a, const void* ca
                             uint32_t lds_bytes, hipStream_t stream) {
   const uint32_t tiles = (uint32_t)((a.W + TILE_W - 1) / TILE_W) * (uint32_t)((a.H + TILE_H - 1) / TILE_H);
   const uint32_t wpb = (uint32_t)threads / 64u;
-  if (precision == 0) {
-    hipError_t e = allow_big_lds(first_hit_kernel<float>, lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((first_hit_kernel<float>), dim3((tiles + wpb - 1) / wpb), dim3(threads), lds_bytes,
-                       stream, a, *static_cast<const CamDev<float>*>(cam));
-  } else {
-    hipError_t e = allow_big_lds(first_hit_kernel<double>, lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((first_hit_kernel<double>), dim3((tiles + wpb - 1) / wpb), dim3(threads), lds_bytes,
-                       stream, a, *static_cast<const CamDev<double>*>(cam));
-  }
-  return hipGetLastError();
+  const uint32_t blocks = (tiles + wpb - 1) / wpb;
+  if (precision == 0)
+    return a.L.wide ? launch_first_hit_t<float, true>(a, cam, blocks, threads, lds_bytes, stream)
+                    : launch_first_hit_t<float, false>(a, cam, blocks, threads, lds_bytes, stream);
+  return a.L.wide ? launch_first_hit_t<double, true>(a, cam, blocks, threads, lds_bytes, stream)
+                  : launch_first_hit_t<double, false>(a, cam, blocks, threads, lds_bytes, stream);
 }
 
 hipError_t launch_resolve(const long long* accum, int32_t W, int32_t H, double inv_samples, float* rgb_mean,

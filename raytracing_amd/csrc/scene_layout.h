@@ -1,26 +1,57 @@
-// scene_layout.h — the on-chip scene image shared by the host flattener and the
-// device kernels.
+// scene_layout.h — the scene image shared by the host flattener and the device
+// kernels.
 //
 // The whole scene (BVH nodes, primitives, materials, textures, Perlin tables)
-// is one byte blob that every workgroup copies into LDS once; the kernels
-// address it by the byte offsets below.  Image texels stay in global memory.
-// Two blobs exist per scene: R = float (the production path) and R = double
-// (the validation path); the layout is the same with sizeof(R) scaled.
+// is one byte blob addressed by the byte offsets below.  Image texels are a
+// separate global array.  Two blobs exist per scene: R = float (the production
+// path) and R = double (the validation path); the layout is the same with
+// sizeof(R) scaled.
+//
+// A blob comes in one of two stores:
+//   on-chip (wide = 0): every workgroup copies the blob into LDS once and
+//     traverses it there; references are 16 bits (<= 4096 primitives per kind,
+//     <= 32768 nodes), and so are the traversal-stack entries;
+//   HBM (wide = 1): for scenes beyond the LDS store (large meshes) the kernels
+//     read the blob where it lies in global memory (L2 / Infinity Cache serve
+//     the hot top of the tree); references and stack entries are 32 bits.
 #pragma once
 #include <stdint.h>
 
 namespace ht {
 
-// ---- child / primitive references (16 bits) -------------------------------
-//   inner node : index                    (bit 15 clear, < 0x8000)
-//   leaf       : 0x8000 | kind << 12 | i  (i = index into the kind's array)
-//   empty      : 0xFFFF
+// ---- child / primitive references ------------------------------------------
+//   on-chip store (16 bits)                   HBM store (32 bits)
+//   inner node : index (< 0x8000)             index (< 0x80000000)
+//   leaf       : 0x8000 | kind << 12 | i      0x80000000 | kind << 28 | i
+//   empty      : 0xFFFF                       0xFFFFFFFF
+// (i = index into the kind's array)
 enum : uint32_t {
   REF_LEAF = 0x8000u,
   REF_EMPTY = 0xFFFFu,
   REF_KIND_SHIFT = 12,
   REF_INDEX_MASK = 0x0FFFu,
+  WREF_LEAF = 0x80000000u,
+  WREF_EMPTY = 0xFFFFFFFFu,
+  WREF_KIND_SHIFT = 28,
+  WREF_INDEX_MASK = 0x0FFFFFFFu,
 };
+template <bool WIDE> struct RefT;
+template <> struct RefT<false> {
+  typedef uint16_t stack_t;
+  static constexpr uint32_t LEAF = REF_LEAF, EMPTY = REF_EMPTY, KIND_SHIFT = REF_KIND_SHIFT,
+                            INDEX_MASK = REF_INDEX_MASK;
+};
+template <> struct RefT<true> {
+  typedef uint32_t stack_t;
+  static constexpr uint32_t LEAF = WREF_LEAF, EMPTY = WREF_EMPTY, KIND_SHIFT = WREF_KIND_SHIFT,
+                            INDEX_MASK = WREF_INDEX_MASK;
+};
+// 32-bit reference -> its 16-bit form (the host builds with 32-bit references)
+inline uint32_t narrow_ref(uint32_t w) {
+  if (w == WREF_EMPTY) return REF_EMPTY;
+  if (w & WREF_LEAF) return REF_LEAF | (((w >> WREF_KIND_SHIFT) & 7u) << REF_KIND_SHIFT) | (w & REF_INDEX_MASK);
+  return w;
+}
 enum : uint32_t {
   KIND_SPHERE = 0,      // c = |o-c|^2 - r^2 evaluated directly
   KIND_XYRECT = 1,
@@ -30,8 +61,9 @@ enum : uint32_t {
   KIND_BIG_SPHERE = 5,  // c = |o|^2 - 2 o.c + K, K = |c|^2 - r^2 from the host in fp64:
                         // well conditioned when r dwarfs the rest of the scene
 };
-constexpr uint32_t MAX_NODES = 0x8000u;
-constexpr uint32_t MAX_PER_KIND = 0x1000u;
+constexpr uint32_t MAX_NODES = 0x8000u;        // on-chip store
+constexpr uint32_t MAX_PER_KIND = 0x1000u;     // on-chip store
+constexpr uint32_t WIDE_MAX_PER_KIND = 1u << 20;
 
 // per-primitive meta word: material << 20 | primitive id
 constexpr uint32_t META_PRIM_MASK = 0xFFFFFu;
@@ -43,8 +75,11 @@ constexpr uint32_t MAX_TEXTURES = 1u << 15;
 // material word 0: kind | texture << 4 ; word 1 (R) : parameter
 // texture record R4: data[0..2], word 3 low 32 bits: kind | child0 << 2 | child1 << 17
 
-constexpr int NODE_REALS = 12;  // lo0.xyz hi0.xyz lo1.xyz hi1.xyz, then one u32: c0 | c1 << 16
-constexpr int STACK_MAX_DEPTH = 30;
+// node: lo0.xyz hi0.xyz lo1.xyz hi1.xyz (12 R), then the two child references:
+// one u32 c0 | c1 << 16 in the on-chip store, two u32 in the HBM store
+constexpr int NODE_REALS = 12;
+constexpr int STACK_MAX_DEPTH = 30;       // on-chip store
+constexpr int WIDE_STACK_MAX_DEPTH = 48;  // HBM store
 
 template <typename R>
 constexpr uint32_t node_stride() {
@@ -71,6 +106,7 @@ struct SceneLayout {
   uint32_t n_nodes, n_sph, n_rect, n_tri, n_mat, n_tex, n_perlin, n_images, n_hoist;
   uint32_t depth;       // levels of traversal stack needed
   uint32_t has_uv_textures; // any Image texture in the scene
+  uint32_t wide;        // 0: on-chip store (LDS, 16-bit references), 1: HBM store (32-bit references)
 };
 
 }  // namespace ht

@@ -163,7 +163,16 @@ class STL:
     triangles: List[Triangle]
 
 
-Hittable = Union[Sphere, XYRect, XZRect, YZRect, Triangle, STL]
+@dataclass
+class Mesh:
+    """An STL world entry held as one array: the same meaning as STL (facets in
+    order, one material), without a Python object per facet.  For large meshes."""
+
+    vertices: np.ndarray = field(repr=False)  # [n, 3, 3]: facet, corner, xyz
+    material: Material = None
+
+
+Hittable = Union[Sphere, XYRect, XZRect, YZRect, Triangle, STL, Mesh]
 
 
 # ---- camera (Camera.scala:3-4) ---------------------------------------------
@@ -353,6 +362,13 @@ class FlatScene:
             elif isinstance(o, STL):
                 for t in o.triangles:
                     add(A.HT_PRIM_TRIANGLE, [*t.vertices[0], *t.vertices[1], *t.vertices[2]], t.material, g)
+            elif isinstance(o, Mesh):
+                v = np.asarray(o.vertices, dtype=np.float64).reshape(-1, 9)
+                m = self._material(o.material)
+                prim_type.extend([A.HT_PRIM_TRIANGLE] * len(v))
+                prim_mat.extend([m] * len(v))
+                prim_data.extend(v.tolist())
+                prim_group.extend([g] * len(v))
             else:
                 raise TypeError(f"not a Hittable: {o!r}")
         if not prim_type:

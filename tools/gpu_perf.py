@@ -16,10 +16,22 @@ ap.add_argument("--counters", type=int, default=1); ap.add_argument("--chunk", t
 a = ap.parse_args()
 ht.set_option("max_blocks_per_cu", a.bpc); ht.set_option("chunk", a.chunk); ht.set_option("block_threads", a.threads); ht.set_option("node_den", a.nden); ht.set_option("wait_ratio_num", a.wnum); ht.set_option("wait_ratio_den", a.wden)
 for name in a.scenes:
-    cam, world = load_scene(f"{SC}/{name}.json")
-    flat = flatten(world)
+    if name.startswith("mesh:"):  # mesh:<n_lat>x<n_lon>: the procedural stand-in for miata.stl
+        from raytracing_amd.meshgen import bumpy_ellipsoid
+        from raytracing_amd.scene import Mesh
+        nl, no = (int(x) for x in name[5:].split("x"))
+        cam, world = load_scene(f"{SC}/dragon.json")
+        t0 = time.time()
+        world = [world[0], Mesh(bumpy_ellipsoid(nl, no), world[1].triangles[0].material)]
+        flat = flatten(world)
+        print(f"{name}: {flat.n_prims} prims, flatten {time.time()-t0:.2f}s", flush=True)
+    else:
+        cam, world = load_scene(f"{SC}/{name}.json")
+        flat = flatten(world)
+    t0 = time.time()
     W, H = (1024, 1024) if name == "cornell" and a.w == 1920 else (a.w, a.h)
     with ht.Scene(flat) as s:
+        print(f"{name}: scene create {time.time()-t0:.2f}s info={s.info()}", flush=True)
         s.render(cam, W, H, 4, precision=a.prec)  # warm-up
         for wt in a.wait:
             ht.set_option("wait_threshold", wt)
