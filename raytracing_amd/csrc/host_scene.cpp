@@ -194,6 +194,33 @@ template <> float round_up<float>(double d) {
   return nextafterf(f, INFINITY);
 }
 
+// ---- IEEE half floats, rounded toward a chosen side --------------------------------
+// Halves are ordered like the signed integer key = +-(bits & 0x7FFF); a binary search
+// over the keys finds the nearest half on the wanted side of d.
+double half_value(int key) {
+  const int m = key < 0 ? -key : key;  // 0 .. 0x7C00 (infinity)
+  const int e = m >> 10, f = m & 0x3FF;
+  double v = e == 0 ? ldexp((double)f, -24) : (e == 31 ? INFINITY : ldexp((double)(f | 0x400), e - 25));
+  return key < 0 ? -v : v;
+}
+uint16_t half_bits(int key) { return key < 0 ? (uint16_t)(0x8000 | -key) : (uint16_t)key; }
+uint16_t half_round_down(double d) {  // largest half <= d
+  int lo = -0x7C00, hi = 0x7C00;      // half_value(lo) = -inf <= d always
+  while (lo < hi) {
+    int mid = lo + (hi - lo + 1) / 2;
+    if (half_value(mid) <= d) lo = mid; else hi = mid - 1;
+  }
+  return half_bits(lo);
+}
+uint16_t half_round_up(double d) {    // smallest half >= d
+  int lo = -0x7C00, hi = 0x7C00;      // half_value(hi) = +inf >= d always
+  while (lo < hi) {
+    int mid = lo + (hi - lo) / 2;
+    if (half_value(mid) >= d) hi = mid; else lo = mid + 1;
+  }
+  return half_bits(lo);
+}
+
 struct Blob {
   std::vector<uint8_t>& b;
   uint32_t reserve(size_t bytes) {
@@ -228,20 +255,30 @@ void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out, 
   L.n_images = (uint32_t)hs.image_width.size();
   L.depth = (uint32_t)hs.depth;
 
-  const uint32_t ns = node_stride<R>();
+  const uint32_t ns = node_stride<R>(wide);
   L.nodes = bl.reserve((size_t)L.n_nodes * ns);
   for (uint32_t i = 0; i < L.n_nodes; ++i) {
     const BvhNode& n = hs.nodes[i];
     uint32_t o = L.nodes + i * ns;
-    for (int c = 0; c < 2; ++c) {
-      for (int a = 0; a < 3; ++a) bl.put<R>(o + (c * 6 + a) * RS, round_down<R>(n.lo[c][a]));
-      for (int a = 0; a < 3; ++a) bl.put<R>(o + (c * 6 + 3 + a) * RS, round_up<R>(n.hi[c][a]));
+    uint32_t co;  // offset of the child references
+    if (sizeof(R) == 4 && wide) {
+      for (int c = 0; c < 2; ++c) {
+        for (int a = 0; a < 3; ++a) bl.put<uint16_t>(o + (c * 6 + a) * 2, half_round_down(n.lo[c][a]));
+        for (int a = 0; a < 3; ++a) bl.put<uint16_t>(o + (c * 6 + 3 + a) * 2, half_round_up(n.hi[c][a]));
+      }
+      co = o + 24;
+    } else {
+      for (int c = 0; c < 2; ++c) {
+        for (int a = 0; a < 3; ++a) bl.put<R>(o + (c * 6 + a) * RS, round_down<R>(n.lo[c][a]));
+        for (int a = 0; a < 3; ++a) bl.put<R>(o + (c * 6 + 3 + a) * RS, round_up<R>(n.hi[c][a]));
+      }
+      co = o + 12 * RS;
     }
     if (wide) {
-      bl.put<uint32_t>(o + 12 * RS, n.child[0]);
-      bl.put<uint32_t>(o + 12 * RS + 4, n.child[1]);
+      bl.put<uint32_t>(co, n.child[0]);
+      bl.put<uint32_t>(co + 4, n.child[1]);
     } else {
-      bl.put<uint32_t>(o + 12 * RS, narrow_ref(n.child[0]) | (narrow_ref(n.child[1]) << 16));
+      bl.put<uint32_t>(co, narrow_ref(n.child[0]) | (narrow_ref(n.child[1]) << 16));
     }
   }
 

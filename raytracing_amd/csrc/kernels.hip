@@ -151,17 +151,39 @@ __device__ __forceinline__ void load_children(const uint8_t* p, uint32_t& c0, ui
     c1 = cc >> 16;
   }
 }
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void unpack_half2(uint32_t w, float& lo, float& hi) {
+  const half2_t h = __builtin_bit_cast(half2_t, w);
+  lo = (float)h.x;
+  hi = (float)h.y;
+}
+// fp32 node.  On chip: 12 floats + packed child references, 64 bytes.  HBM store: 12
+// half-float bounds (rounded outward by the host) + two child references, 32 bytes.
 template <bool WIDE>
 __device__ __forceinline__ void load_node(const Scene& sc, uint32_t idx, float b[12], uint32_t& c0,
                                           uint32_t& c1) {
-  const uint8_t* p = sc.base + sc.L.nodes + (size_t)idx * 64u;
-  float4 a0 = *(const float4*)(p);
-  float4 a1 = *(const float4*)(p + 16);
-  float4 a2 = *(const float4*)(p + 32);
-  load_children<WIDE>(p + 48, c0, c1);
-  b[0] = a0.x; b[1] = a0.y; b[2] = a0.z; b[3] = a0.w;
-  b[4] = a1.x; b[5] = a1.y; b[6] = a1.z; b[7] = a1.w;
-  b[8] = a2.x; b[9] = a2.y; b[10] = a2.z; b[11] = a2.w;
+  if constexpr (WIDE) {
+    const uint8_t* p = sc.base + sc.L.nodes + (size_t)idx * 32u;
+    const uint4 q0 = *(const uint4*)(p);
+    const uint4 q1 = *(const uint4*)(p + 16);
+    unpack_half2(q0.x, b[0], b[1]);
+    unpack_half2(q0.y, b[2], b[3]);
+    unpack_half2(q0.z, b[4], b[5]);
+    unpack_half2(q0.w, b[6], b[7]);
+    unpack_half2(q1.x, b[8], b[9]);
+    unpack_half2(q1.y, b[10], b[11]);
+    c0 = q1.z;
+    c1 = q1.w;
+  } else {
+    const uint8_t* p = sc.base + sc.L.nodes + idx * 64u;
+    const float4 a0 = *(const float4*)(p);
+    const float4 a1 = *(const float4*)(p + 16);
+    const float4 a2 = *(const float4*)(p + 32);
+    load_children<false>(p + 48, c0, c1);
+    b[0] = a0.x; b[1] = a0.y; b[2] = a0.z; b[3] = a0.w;
+    b[4] = a1.x; b[5] = a1.y; b[6] = a1.z; b[7] = a1.w;
+    b[8] = a2.x; b[9] = a2.y; b[10] = a2.z; b[11] = a2.w;
+  }
 }
 template <bool WIDE>
 __device__ __forceinline__ void load_node(const Scene& sc, uint32_t idx, double b[12], uint32_t& c0,

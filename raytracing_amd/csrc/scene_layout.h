@@ -75,15 +75,22 @@ constexpr uint32_t MAX_TEXTURES = 1u << 15;
 // material word 0: kind | texture << 4 ; word 1 (R) : parameter
 // texture record R4: data[0..2], word 3 low 32 bits: kind | child0 << 2 | child1 << 17
 
-// node: lo0.xyz hi0.xyz lo1.xyz hi1.xyz (12 R), then the two child references:
-// one u32 c0 | c1 << 16 in the on-chip store, two u32 in the HBM store
+// node: the bounds of the two children, lo0.xyz hi0.xyz lo1.xyz hi1.xyz, then the child
+// references.
+//   on-chip store: 12 R, then one u32 c0 | c1 << 16            (float 64 B, double 112 B)
+//   HBM store, R = double: 12 doubles, then two u32             (112 B)
+//   HBM store, R = float : 12 IEEE half floats rounded OUTWARD, then two u32 (32 B).
+//     A traversal only needs boxes that contain the children; half-precision bounds
+//     halve the cache footprint and the L2 traffic of a node visit.  Coordinates beyond
+//     the half range become infinite bounds (always hit).  (On chip the conversion
+//     instructions cost more than the LDS bandwidth they save: measured.)
 constexpr int NODE_REALS = 12;
 constexpr int STACK_MAX_DEPTH = 30;       // on-chip store
 constexpr int WIDE_STACK_MAX_DEPTH = 48;  // HBM store
 
 template <typename R>
-constexpr uint32_t node_stride() {
-  return sizeof(R) == 4 ? 64u : 112u;
+constexpr uint32_t node_stride(bool wide) {
+  return sizeof(R) == 4 ? (wide ? 32u : 64u) : 112u;
 }
 
 struct SceneLayout {
