@@ -8,14 +8,15 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 base = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out/prof"
 print(f"# rocprofv3 summary, tag {tag}")
-print("\n## kernel trace (--kernel-trace --stats): bench.py --steps 2 --warmup 1 --no-cpu-baseline")
+wl = sys.argv[3] if len(sys.argv) > 3 else "dragon"
+print(f"\n## kernel trace (--kernel-trace --stats): bench.py --workload {wl} --steps 2 --warmup 1 --no-cpu-baseline")
 for f in glob.glob(f"{base}/trace_{tag}/*/*_kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         print(f"{r['Name'][:90]:90s} calls={r['Calls']:>4s} total_ms={float(r['TotalDurationNs'])/1e6:10.3f} "
               f"avg_ms={float(r['AverageNs'])/1e6:9.4f} pct={float(r['Percentage']):6.2f}")
-print("\n## PMC passes (one rocprofv3 --pmc run each): bench.py --steps 1 --warmup 0 --spp 256 --no-cpu-baseline")
+print(f"\n## PMC passes (one rocprofv3 --pmc run each): bench.py --workload {wl} --steps 1 --warmup 0 --spp 256 --no-cpu-baseline")
 print("## values are sums over the dispatches of the kernel in that run")
-for n in (1, 2, 3, 4):
+for n in (1, 2, 3, 4, 5, 6):
     for f in glob.glob(f"{base}/pmc{n}_{tag}/*/*_counter_collection.csv"):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         disp = collections.defaultdict(set)
