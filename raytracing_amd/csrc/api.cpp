@@ -313,18 +313,31 @@ int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_para
   if (counters) HIP_TRY(hipMemsetAsync(s->d_counters, 0, NUM_COUNTERS * sizeof(unsigned long long), stream));
 
   hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_batch[2] = {nullptr, nullptr};
-  HIP_TRY(hipEventCreate(&ev_start));
-  HIP_TRY(hipEventCreate(&ev_stop));
-  HIP_TRY(hipEventCreateWithFlags(&ev_batch[0], hipEventDisableTiming));
-  HIP_TRY(hipEventCreateWithFlags(&ev_batch[1], hipEventDisableTiming));
   auto cleanup = [&]() {
-    (void)hipEventDestroy(ev_start);
-    (void)hipEventDestroy(ev_stop);
-    (void)hipEventDestroy(ev_batch[0]);
-    (void)hipEventDestroy(ev_batch[1]);
+    if (ev_start) (void)hipEventDestroy(ev_start);
+    if (ev_stop) (void)hipEventDestroy(ev_stop);
+    if (ev_batch[0]) (void)hipEventDestroy(ev_batch[0]);
+    if (ev_batch[1]) (void)hipEventDestroy(ev_batch[1]);
   };
+  {
+    hipError_t ce = hipEventCreate(&ev_start);
+    if (ce == hipSuccess) ce = hipEventCreate(&ev_stop);
+    if (ce == hipSuccess) ce = hipEventCreateWithFlags(&ev_batch[0], hipEventDisableTiming);
+    if (ce == hipSuccess) ce = hipEventCreateWithFlags(&ev_batch[1], hipEventDisableTiming);
+    if (ce != hipSuccess) {
+      (void)hipGetLastError();
+      cleanup();
+      return fail(HT_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(ce));
+    }
+  }
 
-  const int batch = p->batch > 0 ? p->batch : g_default_batch.load();
+  int batch = p->batch > 0 ? p->batch : g_default_batch.load();
+  {
+    // the work queue of one launch is indexed with 32 bits: tiles x sample chunks
+    const int64_t tiles = (int64_t)((p->width + TILE_W - 1) / TILE_W) * ((p->height + TILE_H - 1) / TILE_H);
+    const int64_t max_chunks = std::max<int64_t>(1, ((int64_t)1 << 31) / tiles - 1);
+    batch = (int)std::min<int64_t>(batch, max_chunks * a.chunk);
+  }
   int launches = 0;
   bool cancelled = false;
   hipError_t e = hipEventRecord(ev_start, stream);

@@ -50,6 +50,29 @@ def test_struct_sizes_match_the_header(tmp_path):
     assert got == want
 
 
+def test_options_need_no_device(ht):
+    for name in ("wait_threshold", "max_blocks_per_cu", "default_batch", "chunk", "block_threads", "node_den",
+                 "wait_ratio_num", "wait_ratio_den", "force_hbm_scene"):
+        rc = ht.load().ht_set_option(name.encode(), 0 if name in ("block_threads", "force_hbm_scene") else 8)
+        assert rc == 0, name
+    # back to the defaults the library starts with
+    for name, v in (("wait_threshold", 40), ("max_blocks_per_cu", 8), ("default_batch", 256), ("chunk", 8),
+                    ("block_threads", 0), ("node_den", 2), ("wait_ratio_num", 1000), ("wait_ratio_den", 1)):
+        ht.set_option(name, v)
+    with pytest.raises(ht.HipTraceError) as e:
+        ht.set_option("no_such_option", 1)
+    assert e.value.code == A.HT_E_INVALID and "no_such_option" in str(e.value)
+
+
+def test_frame_calls_reject_null_handles(ht):
+    L = ht.load()
+    assert L.ht_frame_samples(None) == 0
+    assert L.ht_frame_clear(None) == A.HT_E_INVALID
+    assert L.ht_frame_read(None, None, None) == A.HT_E_INVALID
+    L.ht_frame_destroy(None)  # a no-op, like free(NULL)
+    L.ht_scene_destroy(None)
+
+
 def test_no_device_fails_loudly(ht, flat_scene):
     """Without a HIP device the product path must refuse, not fall back."""
     if ht.device_count() > 0:
@@ -65,6 +88,6 @@ def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "raytracing_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".cpp", ".hip", ".h")):
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "oracle/" not in text and "liboracle" not in text, f
