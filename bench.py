@@ -123,6 +123,11 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # build the RCCL communicator now, whatever --warmup says: its set-up takes
+        # seconds and is not part of a frame
+        warm = torch.zeros(1, dtype=torch.int64, device=dev)
+        dist.reduce(warm, dst=0, op=dist.ReduceOp.SUM)
+        torch.cuda.synchronize()
 
     fname, W, H, spp = WORKLOADS[args.workload]
     if args.spp > 0:
