@@ -196,6 +196,17 @@ def main():
         rank_samples = W * H * count * args.steps
         achieved = flops_per_sample * rank_samples / max(ksec, 1e-9) / 1e12
         info = scene.info()
+        # HBM bytes per launch as the PMC passes of the committed profile measured them
+        # (counters cannot be read from inside this process); scaled to this run's launch size
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                tr = json.load(f).get(args.workload)
+            if tr and launches:
+                spp_per_launch = count * args.steps / launches
+                traffic = (tr["fetch_bytes"] + tr["write_bytes"]) * spp_per_launch / tr["spp_per_launch"]
+        except (OSError, ValueError, KeyError):
+            traffic = None
         out = {
             "metric": "Msamples/s (camera paths per second), dragon.json 1920x1080 1024 spp"
             if args.workload == "dragon" else f"Msamples/s (camera paths per second), {args.workload}",
@@ -223,7 +234,9 @@ def main():
                 "peak": FP32_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP32_VALU_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": "HBM bytes per launch (FETCH_SIZE + WRITE_SIZE of profiles/r01_rocprof_summary*.txt); "
+                                "almost all of it is the 64-bit atomic adds that flush tile sums to the frame",
                 "kernel": "render_kernel<float,false>",
                 "flops_per_sample": flops_per_sample,
                 "kernel_ms_per_launch": ksec / max(launches, 1) * 1e3,
