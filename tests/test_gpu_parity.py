@@ -271,12 +271,21 @@ def test_render_frame_mirror(dev, flat_scene):
 
     cam, world, flat = flat_scene("scene")
     img = np.zeros((45, 80), dtype=np.uint32)
-    seen = {}
-    render_frame(cam, world, img, 4, update=lambda j: seen.setdefault("row", j),
-                 finish=lambda t: seen.setdefault("time", t), seed=1)
-    assert seen["row"] == 44 and seen["time"] > 0
+    seen = {"rows": []}
+    render_frame(cam, world, img, 20, update=seen["rows"].append,
+                 finish=lambda t: seen.setdefault("time", t), seed=1, batch=8)
+    assert seen["rows"] == [17, 35, 44] and seen["time"] >= 0  # 8, 16, 20 of 20 samples
     # sky at the top of the picture (row 0 = top): background (0.7, 0.8, 1.0) -> codes 213, 228, 254
     assert img[0, 0] == (213 << 16) | (228 << 8) | 254
-    # a render that is asked to stop immediately leaves the image untouched
-    img2 = np.zeros((45, 80), dtype=np.uint32)
-    render_frame(cam, world, img2, 64, should_break=lambda: True, seed=1)
+    with dev.Scene(flat, device=0) as s:
+        np.testing.assert_array_equal(img, s.render(cam, 80, 45, 20, seed=1)["packed"])
+        # a render that is asked to stop immediately leaves the image untouched
+        img2 = np.zeros((45, 80), dtype=np.uint32)
+        render_frame(cam, s, img2, 64, should_break=lambda: True, seed=1)
+        assert not img2.any()
+        # stopped after two batches: the picture of the samples rendered so far stays
+        calls = []
+        img3 = np.zeros((45, 80), dtype=np.uint32)
+        render_frame(cam, s, img3, 64, should_break=lambda: len(calls) >= 2, update=calls.append, seed=1, batch=8)
+        assert len(calls) == 2
+        np.testing.assert_array_equal(img3, s.render(cam, 80, 45, 16, seed=1)["packed"])
