@@ -1,0 +1,139 @@
+"""Edge cases of the device path against the oracle: ragged picture sizes, the
+depth limit, sample offsets near the top of the range, degenerate geometry, a
+scene built to mix every primitive, material and texture kind in one hierarchy."""
+import numpy as np
+import pytest
+
+from raytracing_amd import _abi as A
+from raytracing_amd.scene import (Camera, Checker, Diffuse, Emission, Glass, Glossy, Perlin, SolidColor, Sphere,
+                                  Triangle, XYRect, XZRect, YZRect, flatten)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(ht):
+    assert ht.device_count() >= 1, "GPU tests need a HIP device; libhiptrace has no CPU path"
+    return ht
+
+
+def close(dev_rgb, ref_rgb, frac=0.99, tol=2e-3):
+    d = np.abs(dev_rgb.astype(np.float64) - ref_rgb).max(axis=-1)
+    return (d < tol).mean() >= frac
+
+
+@pytest.mark.parametrize("W,H", [(2, 2), (3, 5), (9, 7), (8, 8), (17, 64), (65, 3)])
+def test_ragged_picture_sizes(dev, oracle_mod, flat_scene, W, H):
+    """Tiles are 8x8: pictures that do not fill their last tiles, down to the
+    smallest the reference's W-1 / H-1 divisors allow."""
+    cam, _, flat = flat_scene("scene")
+    o = oracle_mod.OracleScene(flat).render(cam, W, H, 3, sampler=oracle_mod.OR_SAMPLER_MATCHED, seed=4)
+    with dev.Scene(flat, device=0) as s:
+        g64 = s.render(cam, W, H, 3, seed=4, precision=A.HT_PRECISION_FP64)
+        g32 = s.render(cam, W, H, 3, seed=4)
+        fh = s.first_hit(cam, W, H, precision=A.HT_PRECISION_FP64)
+    assert np.abs(g64["rgb"] - o["rgb"]).max() <= 3e-6
+    assert close(g32["rgb"], o["rgb"], frac=0.95)
+    ofh = oracle_mod.OracleScene(flat).first_hit(cam, W, H)
+    assert np.array_equal(fh["prim_id"], ofh["prim_id"])
+    assert g32["stats"]["samples"] == W * H * 3
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3, 50, 200])
+def test_depth_limit(dev, oracle_mod, flat_scene, depth):
+    """Camera.ray_color's depth argument (Camera.scala:25-27): a path contributes
+    nothing once `depth` rays have been traced; the closed Cornell box has the
+    long paths that show it."""
+    cam, _, flat = flat_scene("cornell")
+    W, H, spp = 48, 48, 4
+    o = oracle_mod.OracleScene(flat).render(cam, W, H, spp, max_depth=depth, sampler=oracle_mod.OR_SAMPLER_MATCHED, seed=8)
+    with dev.Scene(flat, device=0) as s:
+        g = s.render(cam, W, H, spp, seed=8, max_depth=depth, precision=A.HT_PRECISION_FP64)
+        g32 = s.render(cam, W, H, spp, seed=8, max_depth=depth)
+    assert np.abs(g["rgb"] - o["rgb"]).max() <= 3e-6 * max(1.0, float(o["rgb"].max()))
+    assert close(g32["rgb"], o["rgb"], frac=0.97, tol=2e-3 * max(1.0, float(o["rgb"].max())))
+    if depth == 1:
+        # only what the camera ray itself hits emits: everything but the light is black
+        assert (g["rgb"].max(axis=-1) > 0).mean() < 0.1
+
+
+def test_sample_offsets_up_to_the_top_of_the_range(dev, oracle_mod, flat_scene):
+    """Global sample indices are 31-bit: a shard that starts near the top renders the
+    same paths the oracle renders for those indices."""
+    cam, _, flat = flat_scene("scene")
+    W, H = 40, 24
+    first = 2 ** 31 - 1 - 5
+    o = oracle_mod.OracleScene(flat).render(cam, W, H, 5, sample_offset=first, sampler=oracle_mod.OR_SAMPLER_MATCHED, seed=2)
+    with dev.Scene(flat, device=0) as s:
+        g = s.render(cam, W, H, 5, sample_offset=first, seed=2, precision=A.HT_PRECISION_FP64)
+        h = s.render(cam, W, H, 5, sample_offset=0, seed=2, precision=A.HT_PRECISION_FP64)
+    assert np.abs(g["rgb"] - o["rgb"]).max() <= 3e-6
+    assert np.abs(g["rgb"] - h["rgb"]).max() > 1e-3  # other samples, other picture
+
+
+def mixed_world():
+    """Every primitive kind inside one hierarchy (more than 8 primitives, so nothing but
+    the floor is tested linearly), every material, Checker over Perlin and solid colour."""
+    grey = Diffuse(SolidColor((0.7, 0.7, 0.7)))
+    ranvec, perm = Perlin.tables(3)
+    marble = Diffuse(Checker(3.0, Perlin(2.0, ranvec, perm), SolidColor((0.2, 0.3, 0.9))))
+    lamp = Emission(SolidColor((1.0, 0.9, 0.8)), 6.0)
+    world = [Sphere((0.0, -1000.0, 0.0), 1000.0, marble)]
+    for i in range(5):
+        world.append(Sphere((-4.0 + 2.0 * i, 0.6, 0.5 * i - 1.0), 0.6,
+                            [grey, Glass(SolidColor((1, 1, 1)), 1.5), Glossy(SolidColor((0.9, 0.6, 0.3)), 0.2),
+                             Glossy(SolidColor((0.8, 0.8, 0.8)), 0.0), marble][i]))
+    world += [
+        XYRect(-3.0, 3.0, 0.0, 2.5, -3.0, Glossy(SolidColor((0.9, 0.9, 0.9)), 0.05)),
+        XZRect(-1.0, 1.0, -1.0, 1.0, 4.0, lamp),
+        YZRect(0.0, 2.0, -2.0, 2.0, 5.0, grey),
+        Triangle(((-2.0, 0.0, 2.0), (0.0, 0.0, 2.5), (-1.0, 1.8, 2.2)), grey),
+        Triangle(((1.0, 0.0, 2.0), (3.0, 0.0, 2.0), (2.0, 1.5, 1.5)), Glass(SolidColor((0.9, 1.0, 0.9)), 1.3)),
+        # degenerate input the reference accepts: a triangle of zero area (never hit: det = 0)
+        Triangle(((0.0, 1.0, 0.0), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0)), grey),
+    ]
+    cam = Camera((0.0, 2.5, 9.0), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 40.0, 16 / 9, 0.05, -1.0, (0.05, 0.06, 0.1))
+    return cam, world
+
+
+def test_mixed_scene_first_hit_and_render(dev, oracle_mod):
+    cam, world = mixed_world()
+    flat = flatten(world)
+    W, H = 192, 108
+    osc = oracle_mod.OracleScene(flat, bvh_seed=3)
+    ofh = osc.first_hit(cam, W, H)
+    o = osc.render(cam, 96, 54, 6, sampler=oracle_mod.OR_SAMPLER_MATCHED, seed=12)
+    for hbm in (0, 1):
+        dev.set_option("force_hbm_scene", hbm)
+        try:
+            with dev.Scene(flat, device=0) as s:
+                assert s.info()["n_nodes"] > 0 and s.info()["hbm_store_fp32"] == hbm
+                fh = s.first_hit(cam, W, H, precision=A.HT_PRECISION_FP64)
+                g64 = s.render(cam, 96, 54, 6, seed=12, precision=A.HT_PRECISION_FP64)
+                g32 = s.render(cam, 96, 54, 6, seed=12)
+        finally:
+            dev.set_option("force_hbm_scene", 0)
+        assert np.array_equal(fh["prim_id"], ofh["prim_id"])
+        assert len(np.unique(ofh["prim_id"])) >= 7             # most of the objects are in view
+        assert 11 not in np.unique(fh["prim_id"])                # the zero-area triangle is never hit
+        hit = ofh["prim_id"] >= 0
+        np.testing.assert_allclose(fh["t64"][hit], ofh["t"][hit], rtol=1e-9)
+        scale = max(1.0, float(o["rgb"].max()))
+        assert np.abs(g64["rgb"] - o["rgb"]).max() <= 3e-6 * scale
+        assert close(g32["rgb"], o["rgb"], frac=0.98, tol=2e-3 * scale)
+
+
+def test_single_primitive_worlds(dev, oracle_mod):
+    """A world of one object: the reference builds BVH(only, only) (BVH.scala:30)."""
+    cam = Camera((0.0, 0.0, 5.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 40.0, 1.5, 0.0, -1.0, (0.5, 0.7, 1.0))
+    for prim in (Sphere((0.0, 0.0, 0.0), 1.0, Diffuse(SolidColor((0.8, 0.3, 0.3)))),
+                 Triangle(((-1.0, -1.0, 0.0), (1.0, -1.0, 0.0), (0.0, 1.0, 0.0)), Diffuse(SolidColor((0.3, 0.8, 0.3)))),
+                 XYRect(1.0, -1.0, -1.0, 1.0, 0.0, Emission(SolidColor((1.0, 1.0, 1.0)), 2.0))):  # sides swapped
+        flat = flatten([prim])
+        o = oracle_mod.OracleScene(flat).render(cam, 60, 40, 4, sampler=oracle_mod.OR_SAMPLER_MATCHED, seed=1)
+        ofh = oracle_mod.OracleScene(flat).first_hit(cam, 60, 40)
+        with dev.Scene(flat, device=0) as s:
+            g = s.render(cam, 60, 40, 4, seed=1, precision=A.HT_PRECISION_FP64)
+            fh = s.first_hit(cam, 60, 40, precision=A.HT_PRECISION_FP64)
+        assert np.array_equal(fh["prim_id"], ofh["prim_id"])
+        assert np.abs(g["rgb"] - o["rgb"]).max() <= 3e-6 * max(1.0, float(o["rgb"].max()))
