@@ -26,7 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (scene file, width, height, spp)  — BASELINE.json configs
+    # name: (scene file, width, height, spp): the configurations the metric is quoted on
     "dragon": ("dragon.json", 1920, 1080, 1024),   # STL mesh + BVH, the 1/2/4/8-GPU target
     "random": ("random.json", 1920, 1080, 256),    # 484 spheres, mixed materials
     "cornell": ("cornell.json", 1024, 1024, 4096),  # emissive quad box
@@ -200,7 +200,7 @@ def main():
         # (counters cannot be read from inside this process); scaled to this run's launch size
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 tr = json.load(f).get(args.workload)
             if tr and launches:
                 spp_per_launch = count * args.steps / launches
@@ -235,7 +235,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / FP32_VALU_PEAK_TFLOPS,
                 "traffic": traffic,
-                "traffic_note": "HBM bytes per launch (FETCH_SIZE + WRITE_SIZE of profiles/r01_rocprof_summary*.txt); "
+                "traffic_note": "HBM bytes per launch (FETCH_SIZE + WRITE_SIZE PMC passes, profiles/traffic.json); "
                                 "almost all of it is the 64-bit atomic adds that flush tile sums to the frame",
                 "kernel": "render_kernel<float,false>",
                 "flops_per_sample": flops_per_sample,
