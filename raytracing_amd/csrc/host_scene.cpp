@@ -1,6 +1,6 @@
 // host_scene.cpp — scene validation, the library's own BVH (binned SAH, one
 // primitive per leaf, children's boxes stored in the parent) and the flattening
-// into the on-chip scene image (scene_layout.h).
+// into the scene image (scene_layout.h), for the on-chip store or the HBM store.
 //
 // The reference builds a random-axis median-split hierarchy (BVH.scala:18-33);
 // any correct hierarchy returns the same closest hit, so this one is built for

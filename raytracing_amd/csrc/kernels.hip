@@ -10,14 +10,21 @@
 //    Image texels are the only global reads.  Scenes beyond the LDS store (large
 //    meshes) run the WIDE variants of the same kernels, which read the image where
 //    it lies in global memory and keep only the stacks and tile sums in LDS.
-//  * each wave pulls 8x8-pixel tiles from a global counter; lane = pixel.
+//  * work is a global queue of units, unit = (8x8-pixel tile, chunk of samples);
+//    a wave streams units: dead lanes claim the next (pixel, sample) items of the
+//    wave's current unit, and the next unit is opened while stragglers of the old
+//    one are still in flight.
 //  * lanes are small state machines (TRAV / WAIT / DEAD / DONE).  The wave runs
 //    traversal steps while enough lanes are traversing; when `wait_threshold`
-//    lanes have finished their ray, the wave shades them, regenerates camera
-//    paths for the dead ones (next sample of the same pixel) and goes back to
-//    traversal with the stragglers still in mid-flight, so no lane idles for
-//    the length of the longest path in the wave.
-//  * the per-lane traversal stack lives in LDS, [level][thread] 16-bit node references.
+//    lanes have finished their ray, the wave shades them, starts scattered rays
+//    and new camera paths for the lanes that ended, and goes back to traversal
+//    with the stragglers still in mid-flight, so no lane idles for the length of
+//    the longest path in the wave.
+//  * the per-lane traversal stack lives in LDS, [level][thread], 16-bit node
+//    references (32-bit in the WIDE variants).
+//  * radiance sums are signed 32.32 fixed point: per-wave tile accumulators in LDS
+//    (64-bit LDS atomics), flushed to the frame with 64-bit global atomics, so the
+//    frame does not depend on the order in which paths finish.
 //  * random numbers: Philox4x32-10, counter = (pixel, sample, bounce, 0),
 //    key = seed; one block per event.
 //
