@@ -217,6 +217,22 @@ int ht_render_accumulate(ht_scene* scene, const ht_camera* camera,
                          const ht_render_params* params, int64_t* accum_dev, void* stream,
                          ht_stats* stats_out);
 
+/* One frame rendered by several scene handles at once, one host thread each:
+ * handle k renders the global sample indices [k*S/n, (k+1)*S/n) of every pixel
+ * (S = params->samples, starting at params->sample_offset) into a sum buffer on
+ * its own device; the partial sums are then copied to scenes[0]'s device
+ * (device-to-device, over xGMI between GPUs of one node) and added there, and the
+ * frame is resolved as in ht_render.  The samples of a pixel are a plain sum in the
+ * reference (main.scala:87-91), so any split gives the picture ht_render gives for
+ * the same seed, bit for bit.  The handles must hold the same scene; they may live
+ * on different devices (one per GPU of the node: the single-process form of spp
+ * sharding, for hosts like the JVM that cannot run one process per GPU) or share
+ * one.  params->device is ignored.  stats_out: samples and launches are totals,
+ * seconds_kernel is the slowest shard's. */
+int ht_render_sharded(ht_scene* const* scenes, int32_t n_scenes, const ht_camera* camera,
+                      const ht_render_params* params, float* rgb_linear, uint32_t* rgb_packed,
+                      ht_stats* stats_out);
+
 /* Divide a DEVICE sum buffer by total_samples and write the host pictures as
  * ht_render does (mean, then Vec3.toRGB + row flip). */
 int ht_resolve(ht_scene* scene, const int64_t* accum_dev, int32_t width, int32_t height,

@@ -134,7 +134,7 @@ EXPORTS = [
     "ht_scene_create",
     "ht_scene_destroy",
     "ht_render",
-    "ht_render_accumulate",
+    "ht_render_accumulate", "ht_render_sharded",
     "ht_resolve",
     "ht_resolve_device",
     "ht_frame_create",

@@ -13,6 +13,7 @@
 #include <chrono>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hiptrace.h"
@@ -477,6 +478,127 @@ int ht_render(ht_scene* s, const ht_camera* cam, const ht_render_params* p, floa
     *stats_out = st;
     stats_out->seconds_total =
         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return rc;
+}
+
+int ht_render_sharded(ht_scene* const* scenes, int32_t n, const ht_camera* cam, const ht_render_params* p,
+                      float* rgb_linear, uint32_t* rgb_packed, ht_stats* stats_out) {
+  if (!scenes || !p) return fail(HT_E_INVALID, "NULL argument");
+  if (n < 1 || n > 64) return fail(HT_E_INVALID, "n_scenes must be 1..64");
+  for (int k = 0; k < n; ++k) {
+    if (!scenes[k]) return fail(HT_E_INVALID, "scene %d is NULL", k);
+    for (int j = 0; j < k; ++j)
+      if (scenes[j] == scenes[k]) return fail(HT_E_INVALID, "scene handle %d is listed twice (one render per handle)", k);
+    if (scenes[k]->hs.prim_type.size() != scenes[0]->hs.prim_type.size() ||
+        scenes[k]->hs.nodes.size() != scenes[0]->hs.nodes.size())
+      return fail(HT_E_INVALID, "scene %d is not the scene of handle 0", k);
+  }
+  int rc = check_camera(cam);
+  if (rc != HT_OK) return rc;
+  if (p->width < 2 || p->height < 2)
+    return fail(HT_E_INVALID, "width and height must be >= 2 (the reference divides by W-1 and H-1)");
+  if ((int64_t)p->width * p->height > (int64_t)1 << 30) return fail(HT_E_INVALID, "image too large");
+  if (p->samples < 1) return fail(HT_E_INVALID, "samples must be >= 1");
+  const auto t0 = std::chrono::steady_clock::now();
+  const size_t words = (size_t)p->width * p->height * 3;
+  const size_t bytes = words * sizeof(int64_t);
+
+  struct Shard {
+    int64_t* d_accum = nullptr;
+    ht_render_params params;
+    ht_stats stats;
+    int rc = HT_OK;
+    std::string error;
+  };
+  std::vector<Shard> shards((size_t)n);
+  auto release = [&]() {
+    for (int k = 0; k < n; ++k)
+      if (shards[(size_t)k].d_accum) {
+        DeviceGuard g(scenes[k]->device);
+        (void)hipFree(shards[(size_t)k].d_accum);
+      }
+  };
+  for (int k = 0; k < n; ++k) {
+    Shard& sh = shards[(size_t)k];
+    const int64_t first = (int64_t)k * p->samples / n, last = (int64_t)(k + 1) * p->samples / n;
+    sh.params = *p;
+    sh.params.sample_offset = p->sample_offset + (int32_t)first;
+    sh.params.samples = (int32_t)(last - first);
+    sh.params.device = -1;
+    memset(&sh.stats, 0, sizeof sh.stats);
+    DeviceGuard g(scenes[k]->device);
+    hipError_t e = g.ok ? hipMalloc((void**)&sh.d_accum, bytes) : hipErrorInvalidDevice;
+    if (e == hipSuccess) e = hipMemset(sh.d_accum, 0, bytes);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      release();
+      return fail(HT_E_HIP, "shard %d: allocation of the sum buffer failed: %s", k, hipGetErrorString(e));
+    }
+  }
+  // one host thread per shard: every call sets its own device and blocks until its launches are done
+  {
+    std::vector<std::thread> workers;
+    for (int k = 0; k < n; ++k) {
+      Shard* sh = &shards[(size_t)k];
+      ht_scene* sc = scenes[k];
+      if (sh->params.samples < 1) continue;  // more shards than samples
+      workers.emplace_back([sh, sc, cam]() {
+        sh->rc = ht_render_accumulate(sc, cam, &sh->params, sh->d_accum, nullptr, &sh->stats);
+        if (sh->rc != HT_OK) sh->error = ht_last_error();  // the message is per thread: carry it over
+      });
+    }
+    for (auto& w : workers) w.join();
+  }
+  for (int k = 0; k < n; ++k)
+    if (shards[(size_t)k].rc != HT_OK) {
+      const int code = shards[(size_t)k].rc;
+      const std::string msg = shards[(size_t)k].error;
+      release();
+      return fail(code, "shard %d: %s", k, msg.c_str());
+    }
+  // bring the partial sums to device 0 of the list and add them there
+  {
+    const int dev0 = scenes[0]->device;
+    DeviceGuard g(dev0);
+    if (!g.ok) { release(); return fail(HT_E_NO_DEVICE, "cannot select device %d", dev0); }
+    int64_t* staging = nullptr;
+    hipError_t e = hipSuccess;
+    for (int k = 1; k < n && e == hipSuccess; ++k) {
+      if (shards[(size_t)k].params.samples < 1) continue;
+      const int devk = scenes[k]->device;
+      const long long* src = (const long long*)shards[(size_t)k].d_accum;
+      if (devk != dev0) {
+        // direct device-to-device copies where the link allows them (already enabled, or
+        // not possible: the copy then goes through the host, which is still correct)
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dev0, devk) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(devk, 0);
+        (void)hipGetLastError();
+        if (!staging) e = hipMalloc((void**)&staging, bytes);
+        if (e == hipSuccess) e = hipMemcpyPeer(staging, dev0, shards[(size_t)k].d_accum, devk, bytes);
+        src = (const long long*)staging;
+      }
+      if (e == hipSuccess) e = launch_accum_add((long long*)shards[0].d_accum, src, words, nullptr);
+      if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // staging is reused by the next shard
+    }
+    if (staging) (void)hipFree(staging);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      release();
+      return fail(HT_E_HIP, "combining the shards failed: %s", hipGetErrorString(e));
+    }
+  }
+  rc = ht_resolve(scenes[0], shards[0].d_accum, p->width, p->height, p->samples, rgb_linear, rgb_packed, nullptr);
+  release();
+  if (rc == HT_OK && stats_out) {
+    *stats_out = shards[0].stats;
+    for (int k = 1; k < n; ++k) {
+      const ht_stats& st = shards[(size_t)k].stats;
+      stats_out->samples += st.samples;
+      stats_out->launches += st.launches;
+      stats_out->seconds_kernel = std::max(stats_out->seconds_kernel, st.seconds_kernel);
+    }
+    stats_out->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
   return rc;
 }

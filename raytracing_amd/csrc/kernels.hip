@@ -1122,6 +1122,12 @@ __global__ void resolve_kernel(const long long* __restrict__ accum, int32_t W, i
   if (rgb_packed) rgb_packed[(size_t)((uint32_t)H - 1u - j) * (uint32_t)W + i] = code;
 }
 
+// dst += src: integer sums, so the order in which shards are combined does not matter
+__global__ void accum_add_kernel(long long* __restrict__ dst, const long long* __restrict__ src, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -1202,6 +1208,12 @@ hipError_t launch_first_hit(int precision, const FirstHitArgs& a, const void* ca
                     : launch_first_hit_t<float, false>(a, cam, blocks, threads, lds_bytes, stream);
   return a.L.wide ? launch_first_hit_t<double, true>(a, cam, blocks, threads, lds_bytes, stream)
                   : launch_first_hit_t<double, false>(a, cam, blocks, threads, lds_bytes, stream);
+}
+
+hipError_t launch_accum_add(long long* dst, const long long* src, size_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(accum_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, src, n);
+  return hipGetLastError();
 }
 
 hipError_t launch_resolve(const long long* accum, int32_t W, int32_t H, double inv_samples, float* rgb_mean,

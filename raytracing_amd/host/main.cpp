@@ -17,6 +17,7 @@
 #include <fstream>
 #include <iostream>
 #include <string>
+#include <vector>
 
 #include "scene.hpp"
 
@@ -27,6 +28,7 @@ struct Options {
   bool has_filename = false, has_scene = false, dump = false;
   int width = 400, height = 225, samples = 32;
   uint64_t seed = 0;
+  std::vector<int> devices;  // --devices 0,1,..: HIP devices that share the frame's samples
 };
 
 [[noreturn]] void usage_error(const std::string& msg) {
@@ -65,9 +67,19 @@ Options parse(int argc, char** argv) {
     else if (a == "-s" || a == "--samples") o.samples = to_int("samples", value());
     else if (a == "-d" || a == "--dump") o.dump = true;
     else if (a == "--seed") o.seed = std::stoull(value());
+    else if (a == "--devices") {
+      std::string list = value();
+      size_t at = 0;
+      while (at <= list.size()) {
+        size_t comma = list.find(',', at);
+        if (comma == std::string::npos) comma = list.size();
+        o.devices.push_back(to_int("devices", list.substr(at, comma - at)));
+        at = comma + 1;
+      }
+    }
     else if (a == "--help") {
       std::printf("  -d, --dump\n  -o, --filename  <arg>\n  -h, --height  <arg>\n  -s, --samples  <arg>\n"
-                  "  -w, --width  <arg>\n      --seed  <arg>\n      --help   Show help message\n\n"
+                  "  -w, --width  <arg>\n      --seed  <arg>\n      --devices  <d0,d1,..>\n      --help   Show help message\n\n"
                   " trailing arguments:\n  scene (not required)\n");
       std::exit(0);
     } else if (a.size() > 1 && a[0] == '-' && !(a[1] >= '0' && a[1] <= '9')) usage_error("Unknown option '" + a.substr(a.find_first_not_of('-')) + "'");
@@ -225,7 +237,7 @@ int main(int argc, char** argv) {
         scene->camera, scene->world, img, o.samples,
         [&](int line) { std::printf("\rRendered line [%d/%d]", line + 1, o.height); std::fflush(stdout); },
         [&](double t) { std::printf("\nTime: %s\n", formatDuration(t).c_str()); },
-        [] { return false; }, o.seed);
+        [] { return false; }, o.seed, o.devices);
     std::vector<uint8_t> png = rt::encodePNG(img);
     std::ofstream f(o.filename, std::ios::binary);
     f.write((const char*)png.data(), (std::streamsize)png.size());

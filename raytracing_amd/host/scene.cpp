@@ -356,7 +356,7 @@ FlatScene::FlatScene(const std::vector<Hittable>& world) {
 // ---- renderFrame -----------------------------------------------------------------------------
 void renderFrame(const Camera& camera, const std::vector<Hittable>& world, BufferedImage& img, int samples,
                  const std::function<void(int)>& update, const std::function<void(double)>& finish,
-                 const std::function<bool()>& shouldBreak, uint64_t seed) {
+                 const std::function<bool()>& shouldBreak, uint64_t seed, const std::vector<int>& devices) {
   const auto start = std::chrono::steady_clock::now();
   FlatScene flat(world);
   ht_scene* scene = nullptr;
@@ -369,7 +369,40 @@ void renderFrame(const Camera& camera, const std::vector<Hittable>& world, Buffe
       throw std::runtime_error("libhiptrace: " + msg);
     }
   };
-  check(ht_scene_create(&flat.desc(), -1, &scene));
+  if (devices.size() > 1) {
+    // samples of the frame shared between several devices, one scene handle each
+    std::vector<ht_scene*> scenes;
+    auto drop = [&]() { for (ht_scene* s : scenes) ht_scene_destroy(s); };
+    ht_render_params p{};
+    p.width = img.getWidth();
+    p.height = img.getHeight();
+    p.samples = samples;
+    p.max_depth = 50;
+    p.jitter = 1;
+    p.precision = HT_PRECISION_FP32;
+    p.seed = seed;
+    p.device = -1;
+    const ht_camera cam = camera.to_c();
+    int rc = HT_OK;
+    for (int d : devices) {
+      ht_scene* s = nullptr;
+      rc = ht_scene_create(&flat.desc(), d, &s);
+      if (rc != HT_OK) break;
+      scenes.push_back(s);
+    }
+    if (rc == HT_OK && !shouldBreak())
+      rc = ht_render_sharded(scenes.data(), (int32_t)scenes.size(), &cam, &p, nullptr, img.rgb.data(), nullptr);
+    if (rc != HT_OK) {
+      std::string msg = ht_last_error();
+      drop();
+      throw std::runtime_error("libhiptrace: " + msg);
+    }
+    drop();
+    update(img.getHeight() - 1);
+    finish((double)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - start).count() / 1000.0);
+    return;
+  }
+  check(ht_scene_create(&flat.desc(), devices.empty() ? -1 : devices[0], &scene));
   check(ht_frame_create(scene, img.getWidth(), img.getHeight(), &frame));
   const ht_camera cam = camera.to_c();
   const int batch = 64;  // shouldBreak granularity (the reference polls once per row, main.scala:80)

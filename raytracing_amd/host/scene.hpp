@@ -124,12 +124,15 @@ struct BufferedImage {
 // batches of samples: after each batch `img` holds the picture so far and `update`
 // gets the index of the row the reference would have finished after the same share
 // of the work (height-1 at the end); `finish` gets the seconds taken; `shouldBreak`
-// is polled between batches.  Throws std::runtime_error with the library's message
+// is polled between batches.  `devices`: HIP device ordinals to share the samples of
+// the frame between (ht_render_sharded; one whole-frame call, so `update` comes once);
+// empty or one entry: the progressive single-device path.  Throws std::runtime_error with the library's message
 // if the device path fails (there is no CPU path to fall back to).
 void renderFrame(const Camera& camera, const std::vector<Hittable>& world, BufferedImage& img, int samples,
                  const std::function<void(int)>& update = [](int) {},
                  const std::function<void(double)>& finish = [](double) {},
-                 const std::function<bool()>& shouldBreak = [] { return false; }, uint64_t seed = 0);
+                 const std::function<bool()>& shouldBreak = [] { return false; }, uint64_t seed = 0,
+                 const std::vector<int>& devices = {});
 
 // image codecs of the front-end
 Image decodePNG(const std::vector<uint8_t>& bytes);

@@ -48,6 +48,8 @@ def load() -> C.CDLL:
                             C.POINTER(A.ht_stats)]
     L.ht_render_accumulate.argtypes = [vp, C.POINTER(A.ht_camera), C.POINTER(A.ht_render_params), vp, vp,
                                        C.POINTER(A.ht_stats)]
+    L.ht_render_sharded.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(A.ht_camera), C.POINTER(A.ht_render_params),
+                                    A._pf32, A._pu32, C.POINTER(A.ht_stats)]
     L.ht_resolve.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, A._pf32, A._pu32, vp]
     L.ht_resolve_device.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, vp, vp]
     L.ht_first_hit.argtypes = [vp, C.POINTER(A.ht_camera), C.c_int32, C.c_int32, C.c_int32, A._pf32,
@@ -179,6 +181,20 @@ class Scene:
                                    n.ctypes.data_as(A._pf32), t64.ctypes.data_as(A._pf64),
                                    n64.ctypes.data_as(A._pf64)))
         return {"t": t, "prim_id": pid, "normal": n, "t64": t64, "normal64": n64}
+
+
+def render_sharded(scenes, camera, width, height, samples, **kw) -> dict:
+    """ht_render_sharded: one frame by several Scene handles (one per GPU of the node, or
+    several on one GPU), each rendering its share of the samples per pixel."""
+    p = make_params(width, height, samples, **kw)
+    rgb = np.zeros((height, width, 3), dtype=np.float32)
+    packed = np.zeros((height, width), dtype=np.uint32)
+    st = A.ht_stats()
+    cc = camera.to_c()
+    handles = (C.c_void_p * len(scenes))(*[s.handle for s in scenes])
+    _check(load().ht_render_sharded(handles, len(scenes), C.byref(cc), C.byref(p), rgb.ctypes.data_as(A._pf32),
+                                    packed.ctypes.data_as(A._pu32), C.byref(st)))
+    return {"rgb": rgb, "packed": packed, "stats": st.as_dict()}
 
 
 class Frame:

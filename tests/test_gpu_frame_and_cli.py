@@ -106,3 +106,61 @@ def test_cli_renders_a_large_stl_scene(dev, tmp_path):
         want = s.render(cam, 160, 90, 8, seed=5)["packed"]
     np.testing.assert_array_equal(got, want)
     assert len(np.unique(got)) > 100  # a picture, not a flat colour
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5])
+def test_sharded_render_equals_one_render(dev, flat_scene, n):
+    """ht_render_sharded: n scene handles (here all on device 0; one per GPU on a node)
+    render disjoint sample ranges concurrently; the combined frame is ht_render's, bit
+    for bit, also when there are more handles than samples."""
+    cam, _, flat = flat_scene("dragon")
+    W, H = 128, 72
+    scenes = [dev.Scene(flat, device=0) for _ in range(n)]
+    try:
+        for spp in (7, 3):
+            whole = scenes[0].render(cam, W, H, spp, seed=21)
+            got = dev.render_sharded(scenes, cam, W, H, spp, seed=21)
+            np.testing.assert_array_equal(got["rgb"], whole["rgb"])
+            np.testing.assert_array_equal(got["packed"], whole["packed"])
+            assert got["stats"]["samples"] == W * H * spp
+        off = dev.render_sharded(scenes, cam, W, H, 4, seed=21, sample_offset=3)
+        ref = scenes[0].render(cam, W, H, 4, seed=21, sample_offset=3)
+        np.testing.assert_array_equal(off["rgb"], ref["rgb"])
+    finally:
+        for s in scenes:
+            s.close()
+
+
+def test_sharded_render_errors(dev, flat_scene):
+    cam, _, flat = flat_scene("scene")
+    _, _, other = flat_scene("dragon")
+    with dev.Scene(flat, device=0) as a, dev.Scene(other, device=0) as b:
+        with pytest.raises(dev.HipTraceError) as e:
+            dev.render_sharded([a, a], cam, 32, 18, 2)
+        assert e.value.code == -1 and "twice" in str(e.value)
+        with pytest.raises(dev.HipTraceError) as e:
+            dev.render_sharded([a, b], cam, 32, 18, 2)
+        assert "not the scene" in str(e.value)
+        with pytest.raises(dev.HipTraceError):
+            dev.render_sharded([a], cam, 1, 18, 2)
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="hiptrace-render not built")
+def test_cli_devices_option(dev, flat_scene, tmp_path):
+    """--devices 0,0: two scene handles share the samples (two GPUs on a node would be
+    --devices 0,1); the PNG is the single-device picture."""
+    from PIL import Image
+    out = str(tmp_path / "d.png")
+    r = subprocess.run([BIN, "-o", out, "-w", "96", "-h", "54", "-s", "9", "--seed", "3", "--devices", "0,0",
+                        os.path.join(SCENES, "cornell.json")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "Rendered line [54/54]" in r.stdout
+    im = np.asarray(Image.open(out).convert("RGB")).astype(np.uint32)
+    got = im[..., 0] << 16 | im[..., 1] << 8 | im[..., 2]
+    cam, _, flat = flat_scene("cornell")
+    with dev.Scene(flat, device=0) as s:
+        np.testing.assert_array_equal(got, s.render(cam, 96, 54, 9, seed=3)["packed"])
+    # a device the machine does not have is an error from the library, not a crash
+    r = subprocess.run([BIN, "-o", out, "--devices", "0,4096", os.path.join(SCENES, "cornell.json")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "4096" in r.stderr
