@@ -72,6 +72,8 @@ template <> struct M<float> {
   static __device__ __forceinline__ uint32_t bits_lo(float x) { return __float_as_uint(x); }
   static __device__ __forceinline__ float to_float_down(float x) { return x; }
   static __device__ __forceinline__ float slab_widen() { return 1.0000005f; }
+  static __device__ __forceinline__ float slab_abs() { return 2.3841858e-07f; }  // 2^-22
+  static __device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 };
 
 template <> struct M<double> {
@@ -98,6 +100,8 @@ template <> struct M<double> {
   }
   static __device__ __forceinline__ float to_float_down(double x) { return __double2float_rd(x); }
   static __device__ __forceinline__ double slab_widen() { return 1.0000000000001; }
+  static __device__ __forceinline__ double slab_abs() { return 4.440892098500626e-16; }  // 2^-51
+  static __device__ __forceinline__ double fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 };
 
 template <typename R> struct V3 { R x, y, z; };
@@ -399,11 +403,19 @@ __device__ __forceinline__ void prim_test(const Scene& sc, const Ray<R>& ray, Tr
 // carry no entry distance: with near-child-first descent, culling popped entries
 // against the closest hit saved only ~2.5 % of the box tests on the reference's
 // scenes, less than the LDS it costs.)
+// Both stack operations are branch-free: a pop always reads a valid slot and selects,
+// a push always stores above the top and bumps the count only when it is meant.  The
+// traversal loop is bound by scalar issue (exec-mask bookkeeping), not by its vector
+// work, so nested branches cost more than the spare LDS access; the stack has one slot
+// more than the hierarchy has levels for the store of a full stack.
 template <typename R, bool WIDE>
 __device__ __forceinline__ uint32_t trav_pop(Trav<R>& tv, const typename RefT<WIDE>::stack_t* stack_lane) {
-  if (tv.sp == 0u) return RefT<WIDE>::EMPTY;
-  tv.sp -= blockDim.x;  // stack layout is [level][thread]; sp counts elements, not levels
-  return (uint32_t)stack_lane[tv.sp];
+  const uint32_t BT = blockDim.x;  // stack layout is [level][thread]; sp counts elements, not levels
+  const bool has = tv.sp != 0u;
+  const uint32_t below = has ? tv.sp - BT : 0u;
+  const uint32_t top = (uint32_t)stack_lane[below];
+  tv.sp = below;
+  return has ? top : RefT<WIDE>::EMPTY;
 }
 
 // Inner node: slab-test both children, descend into the nearer one that is hit
@@ -419,17 +431,16 @@ __device__ __forceinline__ void node_step(const Scene& sc, const Ray<R>& ray, Tr
   const bool h0 = slab<R>(ray, b[0], b[1], b[2], b[3], b[4], b[5], t_min, tv.best_t, tn0);
   const bool h1 = slab<R>(ray, b[6], b[7], b[8], b[9], b[10], b[11], t_min, tv.best_t, tn1);
   if (CNT) cnt.v[CTR_BOX] += 2;
-  if (h0 && h1) {
-    const bool swp = tn1 < tn0;
-    const uint32_t nearc = swp ? c1 : c0, farc = swp ? c0 : c1;
-    stack_lane[tv.sp] = (typename RefT<WIDE>::stack_t)farc;
-    tv.sp += BT;
-    tv.cur = nearc;
-  } else if (h0 || h1) {
-    tv.cur = h0 ? c0 : c1;
-  } else {
-    tv.cur = trav_pop<R, WIDE>(tv, stack_lane);
-  }
+  const bool both = h0 && h1, none = !(h0 || h1);
+  const bool swp = tn1 < tn0;                         // meaningful when both are hit
+  const uint32_t farc = swp ? c0 : c1;
+  const uint32_t nearc = both ? (swp ? c1 : c0) : (h0 ? c0 : c1);
+  stack_lane[tv.sp] = (typename RefT<WIDE>::stack_t)farc;  // kept only if the count moves past it
+  const bool has = tv.sp != 0u;
+  const uint32_t below = has ? tv.sp - BT : 0u;
+  const uint32_t top = (uint32_t)stack_lane[below];
+  tv.cur = none ? (has ? top : RefT<WIDE>::EMPTY) : nearc;
+  tv.sp = both ? tv.sp + BT : (none ? below : tv.sp);
 }
 
 // Start of a ray: the hoisted primitives (the same primitive for every lane, so
@@ -795,7 +806,7 @@ enum : uint32_t { ST_TRAV = 0, ST_WAIT = 1, ST_DEAD = 2, ST_DONE = 3 };
 // LDS of a render workgroup: [scene image (on-chip store only)][traversal stacks]
 // [per-wave tile sums]  (a lane pushes at most one entry per level of inner nodes above it)
 __host__ __device__ inline uint32_t stack_bytes(uint32_t threads, uint32_t depth, uint32_t wide) {
-  return (threads * (wide ? 4u : 2u) * (depth > 0u ? depth : 1u) + 15u) & ~15u;
+  return (threads * (wide ? 4u : 2u) * (depth + 1u) + 15u) & ~15u;  // one slot above the deepest push
 }
 __host__ __device__ inline uint32_t image_bytes_in_lds(const SceneLayout& L) { return L.wide ? 0u : L.total_bytes; }
 constexpr uint32_t TILE_PIXELS = TILE_W * TILE_H;       // 64 = one wave
@@ -807,8 +818,14 @@ constexpr uint32_t TILE_ACC_BYTES = TILE_PIXELS * 3u * 8u;
 // dead lanes claim the next (pixel, sample) items of the current unit, and when
 // the unit runs out the wave moves on to the next one at once while the
 // stragglers of the old unit are still in flight.
+// Waves per SIMD the register allocator must leave room for: the plain fp32 variants
+// are held to 80 VGPRs, so that 24 waves fit a CU next to the scene image.
 template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
-__global__ void __launch_bounds__(M<R>::BT) render_kernel(RenderArgs A, CamDev<R> cam) {
+struct MinWaves { static constexpr int value = (sizeof(R) == 4 && !CNT && FEAT == 0u && !WIDE) ? 6 : 1; };
+
+template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
+__global__ void __launch_bounds__(M<R>::BT) __attribute__((amdgpu_waves_per_eu(MinWaves<R, CNT, FEAT, WIDE>::value)))
+render_kernel(RenderArgs A, CamDev<R> cam) {
   extern __shared__ __align__(16) uint8_t lds[];
   typedef RefT<WIDE> RF;
   typedef typename RF::stack_t stack_t;
@@ -998,7 +1015,7 @@ __global__ void __launch_bounds__(M<R>::BT) render_kernel(RenderArgs A, CamDev<R
         const bool inner = state == ST_TRAV && !(tv.cur & RF::LEAF);
         const uint64_t mi = __ballot(inner);
         const uint64_t mt = __ballot(state == ST_TRAV);
-        // leaves wait while at least a third of the travelling lanes still descend
+        // leaves wait while at least 1/node_den of the travelling lanes still descend
         if (mi == 0ull || A.node_den * __popcll(mi) < __popcll(mt)) break;
         if (inner) {
           node_step<R, CNT, WIDE>(sc, ray, tv, stack_lane, t_min, cnt);

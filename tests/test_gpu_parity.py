@@ -240,15 +240,14 @@ def test_error_handling(dev, flat_scene):
         s.render(cam, 16, 16, 1, precision=7)
     # a material index out of range is rejected at scene creation
     bad = flat.prim_material.copy()
-    keep = flat.desc.prim_material
     bad[0] = 999
     flat.desc.prim_material = bad.ctypes.data_as(A._pi32)
     try:
         with pytest.raises(dev.HipTraceError) as e2:
             dev.Scene(flat)
         assert e2.value.code == A.HT_E_INVALID
-    finally:
-        flat.desc.prim_material = keep
+    finally:  # (a pointer read from the struct is a view of the field, not a saved copy)
+        flat.desc.prim_material = flat.prim_material.ctypes.data_as(A._pi32)
     h = C.c_void_p()
     assert dev.load().ht_scene_create(None, 0, C.byref(h)) == A.HT_E_INVALID
     assert dev.load().ht_scene_create(C.byref(flat.desc), 4096, C.byref(h)) == A.HT_E_NO_DEVICE
