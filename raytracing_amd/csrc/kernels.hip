@@ -1023,6 +1023,15 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
           if (CNT) cnt.v[CTR_ACTIVE]++;
         }
         if (CNT) cnt.v[CTR_STEPS]++;
+        // a second step for the lanes that are still at inner nodes, without asking the
+        // wave again: the ballots and counts of the loop head cost as much scalar issue
+        // as half a node step
+        if (state == ST_TRAV && !(tv.cur & RF::LEAF)) {
+          node_step<R, CNT, WIDE>(sc, ray, tv, stack_lane, t_min, cnt);
+          if (tv.cur == RF::EMPTY) state = ST_WAIT;
+          if (CNT) cnt.v[CTR_ACTIVE]++;
+        }
+        if (CNT) cnt.v[CTR_STEPS]++;
       }
       const bool leaf = state == ST_TRAV && (tv.cur & RF::LEAF);
       if (__ballot(leaf) != 0ull) {
