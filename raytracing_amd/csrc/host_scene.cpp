@@ -360,6 +360,24 @@ void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out, 
     bl.put<uint32_t>(L.images + i * 16 + 8, (uint32_t)((uint64_t)hs.image_offset[i] & 0xFFFFFFFFu));
     bl.put<uint32_t>(L.images + i * 16 + 12, (uint32_t)((uint64_t)hs.image_offset[i] >> 32));
   }
+  L.solid_textures_only = 1;
+  for (int t : hs.tex_type) if (t != HT_TEX_SOLID) L.solid_textures_only = 0;
+  L.scatter_diffuse_only = 1;
+  for (int m : hs.mat_type) if (m != HT_MAT_DIFFUSE && m != HT_MAT_EMISSION) L.scatter_diffuse_only = 0;
+  // kinds of primitive the hierarchy holds: what the leaf step has to be able to test
+  {
+    std::vector<uint8_t> hoisted_ref;
+    auto in_hoist = [&](uint32_t r) { return std::find(hs.hoist.begin(), hs.hoist.end(), r) != hs.hoist.end(); };
+    for (size_t pi = 0; pi < hs.prim_ref.size() && !hs.nodes.empty(); ++pi) {
+      const uint32_t r = hs.prim_ref[pi];
+      if (in_hoist(r)) continue;
+      const uint32_t kind = (r >> WREF_KIND_SHIFT) & 7u;
+      if (kind == KIND_SPHERE) L.tree_kinds |= TREE_SPHERES;
+      else if (kind == KIND_BIG_SPHERE) L.tree_kinds |= TREE_SPHERES | TREE_MIXED;
+      else if (kind == KIND_TRIANGLE) L.tree_kinds |= TREE_TRIANGLES;
+      else L.tree_kinds |= TREE_RECTS;
+    }
+  }
   L.n_hoist = (uint32_t)hs.hoist.size();
   L.hoist = bl.reserve((size_t)L.n_hoist * 4);
   for (uint32_t i = 0; i < L.n_hoist; ++i) bl.put<uint32_t>(L.hoist + i * 4, ref_out(hs.hoist[i]));

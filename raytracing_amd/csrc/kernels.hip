@@ -363,40 +363,65 @@ __device__ __forceinline__ void tri_solve(const TriGeom<R>& g, const Ray<R>& ray
 }
 
 // One primitive against the ray; a closer accepted hit replaces tv.best_*.
+// The accepted hit is taken by selects, not branches: the traversal loop is short of
+// scalar issue, not of vector work.
+template <typename R, bool CNT>
+__device__ __forceinline__ void sphere_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t ref,
+                                            uint32_t kind, uint32_t idx, R t_min, Cnt& cnt) {
+  if (CNT) cnt.v[CTR_SPHERE]++;
+  SphereSolve<R> ss;
+  if (sphere_solve<R>(sc, ray, kind, idx, ss)) {
+    R t = (ss.t1 > t_min) ? ss.t1 : ss.t2;
+    const bool ok = t > t_min && t < tv.best_t;
+    tv.best_t = ok ? t : tv.best_t;
+    tv.best_ref = ok ? ref : tv.best_ref;
+  }
+}
+template <typename R, bool CNT>
+__device__ __forceinline__ void triangle_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t ref,
+                                              uint32_t idx, R t_min, Cnt& cnt) {
+  if (CNT) cnt.v[CTR_TRI]++;
+  TriGeom<R> g = load_tri<R>(sc, idx);
+  R det, t, u, v;
+  tri_solve<R>(g, ray, det, t, u, v);
+  R w = (R)1 - u - v;
+  const bool ok = det > (R)1e-6 && t >= t_min && t < tv.best_t && u >= (R)0 && v >= (R)0 && w >= (R)0;
+  tv.best_t = ok ? t : tv.best_t;
+  tv.best_ref = ok ? ref : tv.best_ref;
+}
+template <typename R, bool CNT>
+__device__ __forceinline__ void rect_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t ref,
+                                          uint32_t kind, uint32_t idx, R t_min, Cnt& cnt) {
+  // XY / XZ / YZ rect, Hittable.scala:55-92
+  if (CNT) cnt.v[CTR_RECT]++;
+  RectGeom<R> g = load_rect<R>(sc, idx);
+  R oa, ob, ok_, da, db, dk;
+  rect_axes<R>(kind, ray.o, oa, ob, ok_);
+  rect_axes<R>(kind, ray.d, da, db, dk);
+  R t = (g.k - ok_) * M<R>::rcp(dk);
+  R a = oa + t * da, bb = ob + t * db;
+  const bool ok = t >= t_min && t < tv.best_t && a >= g.a0 && a <= g.a1 && bb >= g.b0 && bb <= g.b1;
+  tv.best_t = ok ? t : tv.best_t;
+  tv.best_ref = ok ? ref : tv.best_ref;
+}
 template <typename R, bool CNT, bool WIDE>
 __device__ __forceinline__ void prim_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t ref,
                                           R t_min, Cnt& cnt) {
   const uint32_t kind = (ref >> RefT<WIDE>::KIND_SHIFT) & 7u, idx = ref & RefT<WIDE>::INDEX_MASK;
-  if (kind == KIND_SPHERE || kind == KIND_BIG_SPHERE) {
-    if (CNT) cnt.v[CTR_SPHERE]++;
-    SphereSolve<R> ss;
-    if (sphere_solve<R>(sc, ray, kind, idx, ss)) {
-      R t = (ss.t1 > t_min) ? ss.t1 : ss.t2;
-      if (t > t_min && t < tv.best_t) { tv.best_t = t; tv.best_ref = ref; }
-    }
-  } else if (kind == KIND_TRIANGLE) {
-    if (CNT) cnt.v[CTR_TRI]++;
-    TriGeom<R> g = load_tri<R>(sc, idx);
-    R det, t, u, v;
-    tri_solve<R>(g, ray, det, t, u, v);
-    R w = (R)1 - u - v;
-    if (det > (R)1e-6 && t >= t_min && t < tv.best_t && u >= (R)0 && v >= (R)0 && w >= (R)0) {
-      tv.best_t = t;
-      tv.best_ref = ref;
-    }
-  } else {  // XY / XZ / YZ rect, Hittable.scala:55-92
-    if (CNT) cnt.v[CTR_RECT]++;
-    RectGeom<R> g = load_rect<R>(sc, idx);
-    R oa, ob, ok, da, db, dk;
-    rect_axes<R>(kind, ray.o, oa, ob, ok);
-    rect_axes<R>(kind, ray.d, da, db, dk);
-    R t = (g.k - ok) * M<R>::rcp(dk);
-    R a = oa + t * da, bb = ob + t * db;
-    if (t >= t_min && t < tv.best_t && a >= g.a0 && a <= g.a1 && bb >= g.b0 && bb <= g.b1) {
-      tv.best_t = t;
-      tv.best_ref = ref;
-    }
-  }
+  if (kind == KIND_TRIANGLE) triangle_test<R, CNT>(sc, ray, tv, ref, idx, t_min, cnt);
+  else if (kind == KIND_SPHERE || kind == KIND_BIG_SPHERE) sphere_test<R, CNT>(sc, ray, tv, ref, kind, idx, t_min, cnt);
+  else rect_test<R, CNT>(sc, ray, tv, ref, kind, idx, t_min, cnt);
+}
+// A leaf of the hierarchy.  The host records which kinds of primitive the hierarchy
+// holds (SceneLayout::tree_kinds, wave-uniform): a mesh or a field of spheres skips the
+// dispatch on the kind altogether.
+template <typename R, bool CNT, bool WIDE>
+__device__ __forceinline__ void leaf_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t ref,
+                                          R t_min, Cnt& cnt) {
+  const uint32_t idx = ref & RefT<WIDE>::INDEX_MASK;
+  if (sc.L.tree_kinds == TREE_TRIANGLES) triangle_test<R, CNT>(sc, ray, tv, ref, idx, t_min, cnt);
+  else if (sc.L.tree_kinds == TREE_SPHERES) sphere_test<R, CNT>(sc, ray, tv, ref, KIND_SPHERE, idx, t_min, cnt);
+  else prim_test<R, CNT, WIDE>(sc, ray, tv, ref, t_min, cnt);
 }
 
 // Next reference from the lane's stack; REF_EMPTY when the stack is empty.  (Entries
@@ -717,7 +742,14 @@ __device__ __forceinline__ bool shade_surface(const Scene& sc, const RenderArgs&
   sf.front = dot(ray.d, h.n_out) < (R)0;          // Hit.front_face
   sf.n = sf.front ? h.n_out : -h.n_out;           // Hit.normal (not normalised)
   sf.p = h.p;
-  V3<R> col = texture_eval<R, CNT, FEAT>(sc, A.texels, tex, ray, h, cnt);
+  V3<R> col;
+  if (sc.L.solid_textures_only) {  // wave-uniform: no texture loop, no kind dispatch
+    typename M<R>::R4 t = load_r4<R>(sc, sc.L.tex, tex);
+    col = mk<R>(t.x, t.y, t.z);
+    if (CNT) cnt.v[CTR_TEX0]++;
+  } else {
+    col = texture_eval<R, CNT, FEAT>(sc, A.texels, tex, ray, h, cnt);
+  }
   if (sf.mkind == 3u) {  // Emission: never scatters, emits on both faces
     deposit<R>(sink, T * (sf.param * col));
     return false;
@@ -730,9 +762,9 @@ __device__ __forceinline__ bool shade_surface(const Scene& sc, const RenderArgs&
 // Returns false when a Glossy bounce is absorbed (Material.scala:18-19).
 template <typename R>
 __device__ __forceinline__ bool scatter_direction(const Surface<R>& sf, const Ray<R>& ray,
-                                                  const uint32_t rnd[4], V3<R>& dir) {
+                                                  const uint32_t rnd[4], V3<R>& dir, bool diffuse_only) {
   const V3<R> n = sf.n;
-  if (sf.mkind == 0u) {  // Diffuse
+  if (diffuse_only || sf.mkind == 0u) {  // Diffuse
     dir = n + unit_vector_from<R>(u01<R>(rnd[0]), u01<R>(rnd[1]));
     return true;
   }
@@ -987,7 +1019,7 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
         T = mk<R>((R)1, (R)1, (R)1);
       } else {
         V3<R> dir;
-        go = scatter_direction<R>(sf, ray, rnd, dir);
+        go = scatter_direction<R>(sf, ray, rnd, dir, sc.L.scatter_diffuse_only != 0u);
         ray.o = sf.p;
         ray.d = dir;
       }
@@ -1036,7 +1068,7 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
       const bool leaf = state == ST_TRAV && (tv.cur & RF::LEAF);
       if (__ballot(leaf) != 0ull) {
         if (leaf) {
-          prim_test<R, CNT, WIDE>(sc, ray, tv, tv.cur, t_min, cnt);
+          leaf_test<R, CNT, WIDE>(sc, ray, tv, tv.cur, t_min, cnt);
           tv.cur = trav_pop<R, WIDE>(tv, stack_lane);
           if (tv.cur == RF::EMPTY) state = ST_WAIT;
           if (CNT) cnt.v[CTR_ACTIVE]++;

@@ -61,6 +61,9 @@ enum : uint32_t {
   KIND_BIG_SPHERE = 5,  // c = |o|^2 - 2 o.c + K, K = |c|^2 - r^2 from the host in fp64:
                         // well conditioned when r dwarfs the rest of the scene
 };
+// SceneLayout::tree_kinds.  TREE_SPHERES means ordinary spheres only: a KIND_BIG_SPHERE
+// inside the hierarchy sets TREE_MIXED as well, which sends leaves through the full dispatch.
+enum : uint32_t { TREE_SPHERES = 1u, TREE_RECTS = 2u, TREE_TRIANGLES = 4u, TREE_MIXED = 8u };
 constexpr uint32_t MAX_NODES = 0x8000u;        // on-chip store
 constexpr uint32_t MAX_PER_KIND = 0x1000u;     // on-chip store
 constexpr uint32_t WIDE_MAX_PER_KIND = 1u << 20;
@@ -113,6 +116,9 @@ struct SceneLayout {
   uint32_t n_nodes, n_sph, n_rect, n_tri, n_mat, n_tex, n_perlin, n_images, n_hoist;
   uint32_t depth;       // levels of traversal stack needed
   uint32_t has_uv_textures; // any Image texture in the scene
+  uint32_t solid_textures_only;   // every texture is a SolidColor
+  uint32_t scatter_diffuse_only;  // every material is Diffuse or Emission (Emission never scatters)
+  uint32_t tree_kinds;  // TREE_* bits: kinds of primitive inside the hierarchy (hoisted ones excluded)
   uint32_t wide;        // 0: on-chip store (LDS, 16-bit references), 1: HBM store (32-bit references)
 };
 
