@@ -309,6 +309,8 @@ int ht_scene_get_info(const ht_scene* scene, ht_scene_info* out);
  *                       waiting lanes / travelling lanes >= num / den
  *   "default_batch"     samples per launch when ht_render_params.batch = 0
  *   "chunk"             samples of one 8x8 tile that form one unit of the work queue
+ *   "chunk_tail"        the same for the last "chunk" samples of a launch (smaller units
+ *                       at the end shorten the tail of the launch)
  *   "force_hbm_scene"   scenes created while this is 1 keep their image in HBM even if it
  *                       would fit on chip (testing the large-scene path on small scenes) */
 int ht_set_option(const char* name, int value);

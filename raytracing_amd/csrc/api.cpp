@@ -71,8 +71,9 @@ std::atomic<int> g_wait_threshold{40};
 std::atomic<int> g_max_blocks_per_cu{8};
 std::atomic<int> g_block_threads{0};  // 0: choose
 std::atomic<int> g_node_den{2}, g_wait_num{1000}, g_wait_den{1};
-std::atomic<int> g_default_batch{256};
+std::atomic<int> g_default_batch{1024};
 std::atomic<int> g_chunk{8};
+std::atomic<int> g_chunk_tail{4};
 std::atomic<int> g_force_hbm{0};  // scenes created while set keep their image in HBM
 
 // Makes `device` current for the lifetime of the object, then restores.
@@ -137,6 +138,7 @@ int ht_set_option(const char* name, int value) {
   if (!strcmp(name, "max_blocks_per_cu")) { g_max_blocks_per_cu = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "default_batch")) { g_default_batch = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "chunk")) { g_chunk = std::max(1, value); return HT_OK; }
+  if (!strcmp(name, "chunk_tail")) { g_chunk_tail = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "block_threads")) { g_block_threads = value; return HT_OK; }
   if (!strcmp(name, "node_den")) { g_node_den = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "wait_ratio_num")) { g_wait_num = std::max(1, value); return HT_OK; }
@@ -298,6 +300,7 @@ int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_para
   a.texels = s->d_texels;
   a.accum = (long long*)accum_dev;
   a.chunk = std::max(1, g_chunk.load());
+  a.chunk_tail = std::min(a.chunk, std::max(1, g_chunk_tail.load()));
   a.tile_counter = s->d_tile_counter;
   a.counters = counters ? s->d_counters : nullptr;
   a.W = p->width;
@@ -336,7 +339,7 @@ int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_para
   {
     // the work queue of one launch is indexed with 32 bits: tiles x sample chunks
     const int64_t tiles = (int64_t)((p->width + TILE_W - 1) / TILE_W) * ((p->height + TILE_H - 1) / TILE_H);
-    const int64_t max_chunks = std::max<int64_t>(1, ((int64_t)1 << 31) / tiles - 1);
+    const int64_t max_chunks = std::max<int64_t>(1, ((int64_t)1 << 31) / tiles - 1 - a.chunk);
     batch = (int)std::min<int64_t>(batch, max_chunks * a.chunk);
   }
   int launches = 0;

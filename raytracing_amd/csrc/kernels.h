@@ -26,6 +26,7 @@ struct RenderArgs {
   int32_t sample_first;    // global index of the first sample of this launch
   int32_t sample_count;    // samples per pixel in this launch
   int32_t chunk;           // samples per work unit
+  int32_t chunk_tail;      // samples per work unit among the last `chunk` samples of the launch
   int32_t max_depth;
   int32_t jitter;
   uint32_t seed_lo, seed_hi;

@@ -880,9 +880,14 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
   const uint32_t tiles_x = (uint32_t)(A.W + TILE_W - 1) / TILE_W;
   const uint32_t tiles_y = (uint32_t)(A.H + TILE_H - 1) / TILE_H;
   const uint32_t n_tiles = tiles_x * tiles_y;
-  const uint32_t chunk = (uint32_t)A.chunk;
-  const uint32_t n_chunks = ((uint32_t)A.sample_count + chunk - 1u) / chunk;
-  const uint32_t n_units = n_tiles * n_chunks;
+  // the last `chunk` samples of the launch are cut into units of `chunk_tail` samples:
+  // the units still running when the queue runs dry decide how long the launch drags on
+  const uint32_t chunk = (uint32_t)A.chunk, chunk_tail = (uint32_t)A.chunk_tail;
+  const uint32_t s_total = (uint32_t)A.sample_count;
+  const uint32_t s_big = s_total > chunk ? s_total - chunk : 0u;        // samples in full-size units
+  const uint32_t n_big = (s_big + chunk - 1u) / chunk;
+  const uint32_t n_small = (s_total - s_big + chunk_tail - 1u) / chunk_tail;
+  const uint32_t n_units = n_tiles * (n_big + n_small);
   const R t_min = (R)0.001;  // Camera.scala:28
   const V3<R> bg = ld3<R>(cam.background);
   Cnt cnt;
@@ -982,8 +987,16 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
         const uint32_t tile = unit % n_tiles, ck = unit / n_tiles;
         tile_x0 = (tile % tiles_x) * TILE_W;
         tile_y0 = (tile / tiles_x) * TILE_H;
-        sample_base = (uint32_t)A.sample_first + ck * chunk;
-        pool_size = TILE_PIXELS * min(chunk, (uint32_t)A.sample_count - ck * chunk);
+        uint32_t first, count;
+        if (ck < n_big) {
+          first = ck * chunk;
+          count = min(chunk, s_big - first);
+        } else {
+          first = s_big + (ck - n_big) * chunk_tail;
+          count = min(chunk_tail, s_total - first);
+        }
+        sample_base = (uint32_t)A.sample_first + first;
+        pool_size = TILE_PIXELS * count;
         next_item = 0;
         epoch++;
         continue;

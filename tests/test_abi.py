@@ -52,11 +52,11 @@ def test_struct_sizes_match_the_header(tmp_path):
 
 def test_options_need_no_device(ht):
     for name in ("wait_threshold", "max_blocks_per_cu", "default_batch", "chunk", "block_threads", "node_den",
-                 "wait_ratio_num", "wait_ratio_den", "force_hbm_scene"):
+                 "wait_ratio_num", "wait_ratio_den", "force_hbm_scene", "chunk_tail"):
         rc = ht.load().ht_set_option(name.encode(), 0 if name in ("block_threads", "force_hbm_scene") else 8)
         assert rc == 0, name
     # back to the defaults the library starts with
-    for name, v in (("wait_threshold", 40), ("max_blocks_per_cu", 8), ("default_batch", 256), ("chunk", 8),
+    for name, v in (("wait_threshold", 40), ("max_blocks_per_cu", 8), ("default_batch", 1024), ("chunk", 8), ("chunk_tail", 4),
                     ("block_threads", 0), ("node_den", 2), ("wait_ratio_num", 1000), ("wait_ratio_den", 1)):
         ht.set_option(name, v)
     with pytest.raises(ht.HipTraceError) as e:
