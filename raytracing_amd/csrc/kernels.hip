@@ -853,7 +853,7 @@ constexpr uint32_t TILE_ACC_BYTES = TILE_PIXELS * 3u * 8u;
 // Waves per SIMD the register allocator must leave room for: the plain fp32 variants
 // are held to 80 VGPRs, so that 24 waves fit a CU next to the scene image.
 template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
-struct MinWaves { static constexpr int value = (sizeof(R) == 4 && !CNT && FEAT == 0u && !WIDE) ? 6 : 1; };
+struct MinWaves { static constexpr int value = (sizeof(R) == 4 && !CNT && FEAT == 0u) ? 6 : 1; };
 
 template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
 __global__ void __launch_bounds__(M<R>::BT) __attribute__((amdgpu_waves_per_eu(MinWaves<R, CNT, FEAT, WIDE>::value)))
