@@ -262,15 +262,16 @@ void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out, 
     uint32_t o = L.nodes + i * ns;
     uint32_t co;  // offset of the child references
     if (sizeof(R) == 4 && wide) {
+      // per axis: lo of child 0, lo of child 1, hi of child 0, hi of child 1
       for (int c = 0; c < 2; ++c) {
-        for (int a = 0; a < 3; ++a) bl.put<uint16_t>(o + (c * 6 + a) * 2, half_round_down(n.lo[c][a]));
-        for (int a = 0; a < 3; ++a) bl.put<uint16_t>(o + (c * 6 + 3 + a) * 2, half_round_up(n.hi[c][a]));
+        for (int a = 0; a < 3; ++a) bl.put<uint16_t>(o + (a * 4 + c) * 2, half_round_down(n.lo[c][a]));
+        for (int a = 0; a < 3; ++a) bl.put<uint16_t>(o + (a * 4 + 2 + c) * 2, half_round_up(n.hi[c][a]));
       }
       co = o + 24;
     } else {
       for (int c = 0; c < 2; ++c) {
-        for (int a = 0; a < 3; ++a) bl.put<R>(o + (c * 6 + a) * RS, round_down<R>(n.lo[c][a]));
-        for (int a = 0; a < 3; ++a) bl.put<R>(o + (c * 6 + 3 + a) * RS, round_up<R>(n.hi[c][a]));
+        for (int a = 0; a < 3; ++a) bl.put<R>(o + (a * 4 + c) * RS, round_down<R>(n.lo[c][a]));
+        for (int a = 0; a < 3; ++a) bl.put<R>(o + (a * 4 + 2 + c) * RS, round_up<R>(n.hi[c][a]));
       }
       co = o + 12 * RS;
     }
