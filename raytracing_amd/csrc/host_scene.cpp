@@ -8,6 +8,7 @@
 // conservative: flat boxes are accepted and every box is rounded outward.
 #include "host_scene.h"
 
+#include <float.h>
 #include <math.h>
 #include <string.h>
 
@@ -203,6 +204,7 @@ double half_value(int key) {
   double v = e == 0 ? ldexp((double)f, -24) : (e == 31 ? INFINITY : ldexp((double)(f | 0x400), e - 25));
   return key < 0 ? -v : v;
 }
+double half_value_of(uint16_t bits) { return half_value((bits & 0x8000) ? -(int)(bits & 0x7FFF) : (int)bits); }
 uint16_t half_bits(int key) { return key < 0 ? (uint16_t)(0x8000 | -key) : (uint16_t)key; }
 uint16_t half_round_down(double d) {  // largest half <= d
   int lo = -0x7C00, hi = 0x7C00;      // half_value(lo) = -inf <= d always
@@ -261,13 +263,32 @@ void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out, 
     const BvhNode& n = hs.nodes[i];
     uint32_t o = L.nodes + i * ns;
     uint32_t co;  // offset of the child references
-    if (sizeof(R) == 4 && wide) {
-      // per axis: lo of child 0, lo of child 1, hi of child 0, hi of child 1
-      for (int c = 0; c < 2; ++c) {
-        for (int a = 0; a < 3; ++a) bl.put<uint16_t>(o + (a * 4 + c) * 2, half_round_down(n.lo[c][a]));
-        for (int a = 0; a < 3; ++a) bl.put<uint16_t>(o + (a * 4 + 2 + c) * 2, half_round_up(n.hi[c][a]));
-      }
-      co = o + 24;
+    // per axis four numbers, one pair for each child: fp32 kernels read (centre 0, centre 1,
+    // half-extent 0, half-extent 1), fp64 kernels (lo 0, lo 1, hi 0, hi 1)
+    if (sizeof(R) == 4) {
+      for (int c = 0; c < 2; ++c)
+        for (int a = 0; a < 3; ++a) {
+          const double lo = n.lo[c][a], hi = n.hi[c][a];
+          double m = 0.5 * (lo + hi), h = -1.0;  // an empty box is never entered: c + |e| > c - |e|
+          if (lo <= hi) {
+            if (wide) {
+              m = half_value_of(half_round_down(std::min(std::max(m, -65504.0), 65504.0)));
+            } else {
+              m = (double)(float)std::min(std::max(m, -(double)FLT_MAX), (double)FLT_MAX);
+            }
+            // the stored centre is exact to the kernel; the half-extent covers the box from
+            // there, plus the rounding of (centre - o)/d -/+ half/|d| in fp32
+            h = std::max(hi - m, m - lo) * (1.0 + ldexp(1.0, -20));
+          }
+          if (wide) {
+            bl.put<uint16_t>(o + (a * 4 + c) * 2, half_round_down(m));
+            bl.put<uint16_t>(o + (a * 4 + 2 + c) * 2, h < 0.0 ? half_round_down(h) : half_round_up(h));
+          } else {
+            bl.put<float>(o + (a * 4 + c) * 4, (float)m);
+            bl.put<float>(o + (a * 4 + 2 + c) * 4, h < 0.0 ? -1.0f : round_up<float>(h));
+          }
+        }
+      co = o + (wide ? 24 : 48);
     } else {
       for (int c = 0; c < 2; ++c) {
         for (int a = 0; a < 3; ++a) bl.put<R>(o + (a * 4 + c) * RS, round_down<R>(n.lo[c][a]));

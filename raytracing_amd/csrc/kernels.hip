@@ -169,7 +169,7 @@ __device__ __forceinline__ void unpack_half2(uint32_t w, float& lo, float& hi) {
   hi = (float)h.y;
 }
 // fp32 node.  On chip: 12 floats + packed child references, 64 bytes.  HBM store: 12
-// half-float bounds (rounded outward by the host) + two child references, 32 bytes.
+// half floats (the half-extents rounded up by the host) + two child references, 32 bytes.
 template <bool WIDE>
 __device__ __forceinline__ void load_node(const Scene& sc, uint32_t idx, float b[12], uint32_t& c0,
                                           uint32_t& c1) {
@@ -220,38 +220,18 @@ __device__ __forceinline__ uint32_t load_u32(const Scene& sc, uint32_t off, uint
 // ---------------------------------------------------------------------------
 // ray + traversal state
 // ---------------------------------------------------------------------------
-// Origin and per-component 1/direction of a ray.  In fp32 they live in three register
-// pairs, (ox, oy), (1/dx, 1/dy), (oz, 1/dz), which the packed two-box slab test reads
-// in place: each subtract or multiply then serves both children of a node.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <typename R>
-struct RayStore {
-  V3<R> o_, inv_;
-  __device__ __forceinline__ V3<R> o() const { return o_; }
-  __device__ __forceinline__ V3<R> inv() const { return inv_; }
-  __device__ __forceinline__ void set_o(V3<R> v) { o_ = v; }
-  __device__ __forceinline__ void set_inv(V3<R> v) { inv_ = v; }
-};
-template <>
-struct RayStore<float> {
-  f32x2 oxy, ixy, ozi;
-  __device__ __forceinline__ V3<float> o() const { V3<float> r; r.x = oxy.x; r.y = oxy.y; r.z = ozi.x; return r; }
-  __device__ __forceinline__ V3<float> inv() const { V3<float> r; r.x = ixy.x; r.y = ixy.y; r.z = ozi.y; return r; }
-  __device__ __forceinline__ void set_o(V3<float> v) { oxy.x = v.x; oxy.y = v.y; ozi.x = v.z; }
-  __device__ __forceinline__ void set_inv(V3<float> v) { ixy.x = v.x; ixy.y = v.y; ozi.y = v.z; }
-};
-template <typename R>
-struct Ray : RayStore<R> {
-  V3<R> d;         // direction, not normalised
-  R a, inv_a, oo;  // |d|^2, 1/|d|^2, |o|^2
+struct Ray {
+  V3<R> o, d, inv;  // inv = 1/d per component
+  R a, inv_a, oo;   // |d|^2, 1/|d|^2, |o|^2
 };
 
 template <typename R>
 __device__ __forceinline__ void ray_setup(Ray<R>& r) {
-  r.set_inv(mk<R>(M<R>::rcp(r.d.x), M<R>::rcp(r.d.y), M<R>::rcp(r.d.z)));
+  r.inv = mk<R>(M<R>::rcp(r.d.x), M<R>::rcp(r.d.y), M<R>::rcp(r.d.z));
   r.a = dot(r.d, r.d);
   r.inv_a = M<R>::rcp(r.a);
-  r.oo = dot(r.o(), r.o());
+  r.oo = dot(r.o, r.o);
 }
 
 template <typename R>
@@ -278,10 +258,9 @@ struct Cnt {
 template <typename R>
 __device__ __forceinline__ bool slab(const Ray<R>& r, R lox, R loy, R loz, R hix, R hiy, R hiz,
                                      R t_min, R t_far, R& tn) {
-  const V3<R> o = r.o(), inv = r.inv();
-  R x0 = (lox - o.x) * inv.x, x1 = (hix - o.x) * inv.x;
-  R y0 = (loy - o.y) * inv.y, y1 = (hiy - o.y) * inv.y;
-  R z0 = (loz - o.z) * inv.z, z1 = (hiz - o.z) * inv.z;
+  R x0 = (lox - r.o.x) * r.inv.x, x1 = (hix - r.o.x) * r.inv.x;
+  R y0 = (loy - r.o.y) * r.inv.y, y1 = (hiy - r.o.y) * r.inv.y;
+  R z0 = (loz - r.o.z) * r.inv.z, z1 = (hiz - r.o.z) * r.inv.z;
   R nx = M<R>::fmin(x0, x1), fx = M<R>::fmax(x0, x1);
   R ny = M<R>::fmin(y0, y1), fy = M<R>::fmax(y0, y1);
   R nz = M<R>::fmin(z0, z1), fz = M<R>::fmax(z0, z1);
@@ -292,66 +271,29 @@ __device__ __forceinline__ bool slab(const Ray<R>& r, R lox, R loy, R loz, R hix
   return tn <= tf;
 }
 
-// a - p[HALF] and a * p[HALF] on both halves of a: one packed instruction each.  Written
-// as instructions because the compiler, left to itself, keeps a register pair per
-// broadcast value (twelve registers for a ray instead of six).
-template <int HALF>
-__device__ __forceinline__ f32x2 pk_sub_half(f32x2 a, f32x2 p) {
-  f32x2 r;
-  if (HALF == 0)
-    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(p));
-  else
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(p));
-  return r;
-}
-template <int HALF>
-__device__ __forceinline__ f32x2 pk_mul_half(f32x2 a, f32x2 p) {
-  f32x2 r;
-  if (HALF == 0)
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(p));
-  else
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(p));
-  return r;
-}
-
-__device__ __forceinline__ float v_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float v_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float v_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ float v_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-// max(min(a, b), 0.001f): the ray's t_min (Camera.scala:28) folded into one axis' entry distance
-__device__ __forceinline__ float v_min_tmin(float a, float b) {
-  float r;
-  asm("v_min_f32 %0, %1, %2\n\tv_max_f32 %0, 0x3a83126f, %0" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
 // The same test for the two children of an inner node at once.  b = the node's bounds as
-// the scene image stores them: per axis (lo child 0, lo child 1, hi child 0, hi child 1),
-// so that in fp32 each subtract and multiply is one packed instruction for both children.
+// the scene image stores them, per axis four numbers, one pair for each child:
+//   fp64: (lo child 0, lo child 1, hi child 0, hi child 1);
+//   fp32: (centre 0, centre 1, half-extent 0, half-extent 1), the half-extent rounded up
+//         and widened by the host so that it also covers the rounding of this arithmetic.
+// With c = (centre - o)/d and e = half/|d| the slab is [c - e, c + e]: five adds and
+// multiplies per axis and child and no min/max to order the two planes (on gfx950 an
+// fp32 add or multiply issues in about half the cycles of a min, max, compare or select).
 template <typename R>
 __device__ __forceinline__ void slab2(const Ray<R>& r, const R b[12], R t_min, R t_far, R& tn0,
                                       R& tn1, bool& h0, bool& h1) {
   if constexpr (sizeof(R) == 4) {
-    // (bounds - origin) * (1/direction): the origin or reciprocal is one half of a register
-    // pair, read for both halves of the result through the operand-select bits
-    const f32x2 x0 = pk_mul_half<0>(pk_sub_half<0>(f32x2{b[0], b[1]}, r.oxy), r.ixy);
-    const f32x2 x1 = pk_mul_half<0>(pk_sub_half<0>(f32x2{b[2], b[3]}, r.oxy), r.ixy);
-    const f32x2 y0 = pk_mul_half<1>(pk_sub_half<1>(f32x2{b[4], b[5]}, r.oxy), r.ixy);
-    const f32x2 y1 = pk_mul_half<1>(pk_sub_half<1>(f32x2{b[6], b[7]}, r.oxy), r.ixy);
-    const f32x2 z0 = pk_mul_half<1>(pk_sub_half<0>(f32x2{b[8], b[9]}, r.ozi), r.ozi);
-    const f32x2 z1 = pk_mul_half<1>(pk_sub_half<0>(f32x2{b[10], b[11]}, r.ozi), r.ozi);
-    // min/max as instructions too: on a value that comes out of an asm statement the
-    // compiler would first spend an instruction to quiet a signalling NaN that cannot
-    // be there (0 * inf gives a quiet one, which v_min/v_max drop like fmin/fmax do)
-    const float nx0 = v_min(x0.x, x1.x), ny0 = v_min(y0.x, y1.x), nz0 = v_min_tmin(z0.x, z1.x);
-    const float nx1 = v_min(x0.y, x1.y), ny1 = v_min(y0.y, y1.y), nz1 = v_min_tmin(z0.y, z1.y);
-    const float fx0 = v_max(x0.x, x1.x), fy0 = v_max(y0.x, y1.x), fz0 = v_max(z0.x, z1.x);
-    const float fx1 = v_max(x0.y, x1.y), fy1 = v_max(y0.y, y1.y), fz1 = v_max(z0.y, z1.y);
-    tn0 = v_max3(nx0, ny0, nz0);
-    tn1 = v_max3(nx1, ny1, nz1);
+    const float aix = __builtin_fabsf(r.inv.x), aiy = __builtin_fabsf(r.inv.y), aiz = __builtin_fabsf(r.inv.z);
+    const float cx0 = (b[0] - r.o.x) * r.inv.x, cx1 = (b[1] - r.o.x) * r.inv.x, ex0 = b[2] * aix, ex1 = b[3] * aix;
+    const float cy0 = (b[4] - r.o.y) * r.inv.y, cy1 = (b[5] - r.o.y) * r.inv.y, ey0 = b[6] * aiy, ey1 = b[7] * aiy;
+    const float cz0 = (b[8] - r.o.z) * r.inv.z, cz1 = (b[9] - r.o.z) * r.inv.z, ez0 = b[10] * aiz, ez1 = b[11] * aiz;
+    tn0 = __builtin_fmaxf(__builtin_fmaxf(cx0 - ex0, cy0 - ey0), __builtin_fmaxf(cz0 - ez0, t_min));
+    tn1 = __builtin_fmaxf(__builtin_fmaxf(cx1 - ex1, cy1 - ey1), __builtin_fmaxf(cz1 - ez1, t_min));
+    const float tf0 = __builtin_fminf(__builtin_fminf(cx0 + ex0, cy0 + ey0), cz0 + ez0);
+    const float tf1 = __builtin_fminf(__builtin_fminf(cx1 + ex1, cy1 + ey1), cz1 + ez1);
     const float w = M<float>::slab_widen();
-    h0 = tn0 <= __builtin_fminf(v_min3(fx0, fy0, fz0) * w, t_far);
-    h1 = tn1 <= __builtin_fminf(v_min3(fx1, fy1, fz1) * w, t_far);
+    h0 = tn0 <= __builtin_fminf(tf0 * w, t_far);
+    h1 = tn1 <= __builtin_fminf(tf1 * w, t_far);
   } else {
     h0 = slab<R>(r, b[0], b[4], b[8], b[2], b[6], b[10], t_min, t_far, tn0);
     h1 = slab<R>(r, b[1], b[5], b[9], b[3], b[7], b[11], t_min, t_far, tn1);
@@ -375,14 +317,14 @@ __device__ __forceinline__ bool sphere_solve(const Scene& sc, const Ray<R>& ray,
   o.cen = mk<R>(s.x, s.y, s.z);
   o.rad = s.w;
   o.big = kind == KIND_BIG_SPHERE;
-  V3<R> oc = ray.o() - o.cen;
+  V3<R> oc = ray.o - o.cen;
   R hb = dot(oc, ray.d);
   o.l = oc - (hb * ray.inv_a) * ray.d;
   const R r2 = o.rad * o.rad;
   R c;
   if (o.big) {
     R K = *(const R*)(sc.base + sc.L.sph_k + idx * (uint32_t)sizeof(R));
-    c = ray.oo - (R)2 * dot(ray.o(), o.cen) + K;
+    c = ray.oo - (R)2 * dot(ray.o, o.cen) + K;
   } else {
     c = dot(oc, oc) - r2;
   }
@@ -440,7 +382,7 @@ __device__ __forceinline__ TriGeom<R> load_tri(const Scene& sc, uint32_t idx) {
 template <typename R>
 __device__ __forceinline__ void tri_solve(const TriGeom<R>& g, const Ray<R>& ray, R& det, R& t, R& u,
                                           R& v) {
-  V3<R> ao = ray.o() - g.A;
+  V3<R> ao = ray.o - g.A;
   V3<R> dao = cross(ao, ray.d);
   det = -dot(ray.d, g.n);
   R inv_det = M<R>::rcp(det);
@@ -483,7 +425,7 @@ __device__ __forceinline__ void rect_test(const Scene& sc, const Ray<R>& ray, Tr
   if (CNT) cnt.v[CTR_RECT]++;
   RectGeom<R> g = load_rect<R>(sc, idx);
   R oa, ob, ok_, da, db, dk;
-  rect_axes<R>(kind, ray.o(), oa, ob, ok_);
+  rect_axes<R>(kind, ray.o, oa, ob, ok_);
   rect_axes<R>(kind, ray.d, da, db, dk);
   R t = (g.k - ok_) * M<R>::rcp(dk);
   R a = oa + t * da, bb = ob + t * db;
@@ -607,7 +549,7 @@ __device__ __forceinline__ HitGeom<R> hit_geometry(const Scene& sc, const Ray<R>
   HitGeom<R> h;
   h.kind = (ref >> RefT<WIDE>::KIND_SHIFT) & 7u;
   h.idx = ref & RefT<WIDE>::INDEX_MASK;
-  h.p = ray.o() + t * ray.d;
+  h.p = ray.o + t * ray.d;
   if (h.kind == KIND_SPHERE || h.kind == KIND_BIG_SPHERE) {
     // outward normal (p - center)/radius (Hittable.scala:44).  For an ordinary
     // sphere p - center is rebuilt from the closest-approach offset and the
@@ -656,7 +598,7 @@ __device__ __forceinline__ void hit_uv(const Scene& sc, const Ray<R>& ray, const
     // (Hittable.scala:44, 46 both pass r.at(t1))
     SphereSolve<R> ss;
     sphere_solve<R>(sc, ray, h.kind, h.idx, ss);
-    V3<R> q = M<R>::rcp(ss.rad) * (ss.big ? (ray.o() + ss.t1 * ray.d) - ss.cen : ss.l - ss.s * ray.d);
+    V3<R> q = M<R>::rcp(ss.rad) * (ss.big ? (ray.o + ss.t1 * ray.d) - ss.cen : ss.l - ss.s * ray.d);
     const R PI = (R)3.14159265358979323846;
     R phi = M<R>::atan2(q.z, q.x);
     R theta = M<R>::asin(M<R>::fmin(M<R>::fmax(q.y, (R)-1), (R)1));
@@ -905,7 +847,7 @@ __device__ __forceinline__ void camera_ray(const RenderArgs& A, const CamDev<R>&
   R s = ((R)i + xi1) / (R)(A.W - 1);
   R t = ((R)j + xi2) / (R)(A.H - 1);
   V3<R> origin = ld3<R>(cam.origin);
-  ray.set_o(origin + offset);
+  ray.o = origin + offset;
   ray.d = ld3<R>(cam.llc) + s * ld3<R>(cam.horizontal) + t * ld3<R>(cam.vertical) - origin - offset;
 }
 
@@ -1001,9 +943,7 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
   V3<R> T = mk<R>((R)1, (R)1, (R)1);
   uint32_t state = ST_DEAD;
   uint32_t my_epoch = 0, pix = 0, pixel = 0, sample = 0, bounce = 0;
-  ray.d = mk<R>((R)0, (R)0, (R)0);
-  ray.set_o(ray.d);
-  ray.set_inv(ray.d);
+  ray.o = ray.d = ray.inv = mk<R>((R)0, (R)0, (R)0);
   ray.a = ray.inv_a = ray.oo = (R)0;
   trav_begin<R, WIDE>(tv);
 
@@ -1122,7 +1062,7 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
       } else {
         V3<R> dir;
         go = scatter_direction<R>(sf, ray, rnd, dir, sc.L.scatter_diffuse_only != 0u);
-        ray.set_o(sf.p);
+        ray.o = sf.p;
         ray.d = dir;
       }
       if (go) {

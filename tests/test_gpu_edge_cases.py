@@ -137,3 +137,37 @@ def test_single_primitive_worlds(dev, oracle_mod):
             fh = s.first_hit(cam, 60, 40, precision=A.HT_PRECISION_FP64)
         assert np.array_equal(fh["prim_id"], ofh["prim_id"])
         assert np.abs(g["rgb"] - o["rgb"]).max() <= 3e-6 * max(1.0, float(o["rgb"].max()))
+
+
+def test_axis_parallel_rays(dev, oracle_mod):
+    """Rays with direction components that are exactly zero (1/d = inf in the box test):
+    a camera looking straight down an axis, odd picture sizes so that the middle column
+    and row have d.x = 0 and d.y = 0.  First hits equal the oracle's in both scene stores."""
+    from raytracing_amd.meshgen import bumpy_ellipsoid
+    from raytracing_amd.scene import Mesh
+    grey = Diffuse(SolidColor((0.7, 0.7, 0.7)))
+    world = [Sphere((0.0, -1001.5, 0.0), 1000.0, grey), Mesh(bumpy_ellipsoid(12, 24), grey)]
+    world += [Sphere((0.5 * i - 2.0, 0.0, 1.5), 0.2, grey) for i in range(9)]  # centres on the plane y = 0
+    flat = flatten(world)
+    for look_from, vup in (((0.0, 0.0, 6.0), (0.0, 1.0, 0.0)), ((6.0, 0.0, 0.0), (0.0, 1.0, 0.0)),
+                           ((0.0, 6.0, 0.0), (0.0, 0.0, 1.0))):
+        cam = Camera(look_from, (0.0, 0.0, 0.0), vup, 40.0, 1.0, 0.0, -1.0, (0.5, 0.7, 1.0))
+        W = H = 65
+        ofh = oracle_mod.OracleScene(flat).first_hit(cam, W, H)
+        o = oracle_mod.OracleScene(flat).render(cam, W, H, 2, sampler=oracle_mod.OR_SAMPLER_MATCHED, seed=6)
+        for hbm in (0, 1):
+            dev.set_option("force_hbm_scene", hbm)
+            try:
+                with dev.Scene(flat, device=0) as s:
+                    fh = s.first_hit(cam, W, H)
+                    fh64 = s.first_hit(cam, W, H, precision=A.HT_PRECISION_FP64)
+                    g64 = s.render(cam, W, H, 2, seed=6, precision=A.HT_PRECISION_FP64)
+            finally:
+                dev.set_option("force_hbm_scene", 0)
+            assert np.array_equal(fh64["prim_id"], ofh["prim_id"])
+            # fp32 may differ from fp64 on silhouettes, never on the axis-parallel middle row and column
+            assert np.array_equal(fh["prim_id"][H // 2, :], ofh["prim_id"][H // 2, :])
+            assert np.array_equal(fh["prim_id"][:, W // 2], ofh["prim_id"][:, W // 2])
+            assert (fh["prim_id"] != ofh["prim_id"]).mean() < 0.01
+            assert np.abs(g64["rgb"] - o["rgb"]).max() <= 3e-6
+        assert len(np.unique(ofh["prim_id"][H // 2, :])) >= 3  # the middle row sees several objects
