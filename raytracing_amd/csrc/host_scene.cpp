@@ -423,7 +423,7 @@ bool texture_acyclic(const HostScene& hs, int t, int depth) {
 
 // LDS a 256-thread workgroup needs beside the image: stacks + tile sums (kernels.hip)
 static uint32_t lds_beside_image(uint32_t depth) {
-  return ((256u * 2u * (depth + 1u) + 15u) & ~15u) + (256u / 64u) * 64u * 3u * 8u;
+  return ((256u * 2u * (depth + 2u) + 15u) & ~15u) + (256u / 64u) * 64u * 3u * 8u;
 }
 
 int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err, const BuildOptions& opt) {
@@ -630,12 +630,12 @@ int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err, co
     // a hierarchy that can live on chip gets the on-chip depth bound; a larger one
     // gets the deeper bound of the HBM store
     const bool small = fits_refs16 && (uint32_t)(nb - 1) <= MAX_NODES && !opt.force_hbm;
-    // HBM store: every level costs 4 bytes of LDS per thread, and with 19 levels (20
+    // HBM store: every level costs 4 bytes of LDS per thread, and with 18 levels (20
     // stack slots) two 768-thread workgroups still fit a CU (24 waves; measured +11 % at
     // 100 k triangles over the 23 levels the SAH tree would take, same number of box tests)
-    int wide_levels = 2;
-    while ((1 << std::min(wide_levels - 2, 30)) < nb && wide_levels < WIDE_STACK_MAX_DEPTH) wide_levels++;
-    wide_levels = std::min(WIDE_STACK_MAX_DEPTH, std::max(19, wide_levels));
+    int wide_levels = 1;
+    while ((1 << std::min(wide_levels - 1, 30)) < nb && wide_levels < WIDE_STACK_MAX_DEPTH) wide_levels++;
+    wide_levels = std::min(WIDE_STACK_MAX_DEPTH, std::max(18, wide_levels));
     b.build(0, nb, small ? STACK_MAX_DEPTH : wide_levels, 0, rb);
     hs.depth = b.max_level;
   }

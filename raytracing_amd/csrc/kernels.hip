@@ -237,7 +237,7 @@ __device__ __forceinline__ void ray_setup(Ray<R>& r) {
 template <typename R>
 struct Trav {
   uint32_t cur;       // reference being processed; REF_EMPTY when the ray is finished
-  uint32_t sp;        // stack elements in use: level * blockDim.x
+  uint32_t sp;        // stack elements in use, the REF_EMPTY at the bottom included: level * blockDim.x
   uint32_t best_ref;  // REF_EMPTY = no hit yet
   R best_t;
 };
@@ -245,7 +245,7 @@ struct Trav {
 template <typename R, bool WIDE>
 __device__ __forceinline__ void trav_begin(Trav<R>& tv) {
   tv.cur = 0;  // root is inner node 0
-  tv.sp = 0;
+  tv.sp = blockDim.x;  // level 0 of every lane's stack holds REF_EMPTY for good
   tv.best_ref = RefT<WIDE>::EMPTY;
   tv.best_t = M<R>::inf();
 }
@@ -453,23 +453,20 @@ __device__ __forceinline__ void leaf_test(const Scene& sc, const Ray<R>& ray, Tr
   else prim_test<R, CNT, WIDE>(sc, ray, tv, ref, t_min, cnt);
 }
 
-// Next reference from the lane's stack; REF_EMPTY when the stack is empty.  (Entries
-// carry no entry distance: with near-child-first descent, culling popped entries
-// against the closest hit saved only ~2.5 % of the box tests on the reference's
-// scenes, less than the LDS it costs.)
-// Both stack operations are branch-free: a pop always reads a valid slot and selects,
-// a push always stores above the top and bumps the count only when it is meant.  The
-// traversal loop is bound by scalar issue (exec-mask bookkeeping), not by its vector
-// work, so nested branches cost more than the spare LDS access; the stack has one slot
-// more than the hierarchy has levels for the store of a full stack.
+// Next reference from the lane's stack.  (Entries carry no entry distance: with
+// near-child-first descent, culling popped entries against the closest hit saved only
+// ~2.5 % of the box tests on the reference's scenes, less than the LDS it costs.)
+// Level 0 of a stack holds REF_EMPTY, written once per kernel: the pop that finds the
+// stack empty reads it like any other entry and the traversal ends, without a compare
+// and select on every pop.  A push always stores above the top and bumps the count only
+// when it is meant; the stack has two slots more than the hierarchy has levels (the
+// REF_EMPTY below, the store of a full stack above).  On gfx950 a compare or select
+// issues at half the rate of an add, and the loop is also short of scalar issue, so both
+// operations are free of branches.
 template <typename R, bool WIDE>
 __device__ __forceinline__ uint32_t trav_pop(Trav<R>& tv, const typename RefT<WIDE>::stack_t* stack_lane) {
-  const uint32_t BT = blockDim.x;  // stack layout is [level][thread]; sp counts elements, not levels
-  const bool has = tv.sp != 0u;
-  const uint32_t below = has ? tv.sp - BT : 0u;
-  const uint32_t top = (uint32_t)stack_lane[below];
-  tv.sp = below;
-  return has ? top : RefT<WIDE>::EMPTY;
+  tv.sp -= blockDim.x;  // stack layout is [level][thread]; sp counts elements, not levels
+  return (uint32_t)stack_lane[tv.sp];
 }
 
 // Inner node: slab-test both children, descend into the nearer one that is hit
@@ -478,6 +475,9 @@ template <typename R, bool CNT, bool WIDE>
 __device__ __forceinline__ void node_step(const Scene& sc, const Ray<R>& ray, Trav<R>& tv,
                                           typename RefT<WIDE>::stack_t* stack_lane, R t_min, Cnt& cnt) {
   const uint32_t BT = blockDim.x;
+  // what a pop would return, read before the arithmetic so that its latency hides there
+  const uint32_t below = tv.sp - BT;
+  const uint32_t top = (uint32_t)stack_lane[below];
   R b[12];
   uint32_t c0, c1;
   load_node<WIDE>(sc, tv.cur, b, c0, c1);
@@ -490,10 +490,7 @@ __device__ __forceinline__ void node_step(const Scene& sc, const Ray<R>& ray, Tr
   const uint32_t farc = swp ? c0 : c1;
   const uint32_t nearc = both ? (swp ? c1 : c0) : (h0 ? c0 : c1);
   stack_lane[tv.sp] = (typename RefT<WIDE>::stack_t)farc;  // kept only if the count moves past it
-  const bool has = tv.sp != 0u;
-  const uint32_t below = has ? tv.sp - BT : 0u;
-  const uint32_t top = (uint32_t)stack_lane[below];
-  tv.cur = none ? (has ? top : RefT<WIDE>::EMPTY) : nearc;
+  tv.cur = none ? top : nearc;
   tv.sp = both ? tv.sp + BT : (none ? below : tv.sp);
 }
 
@@ -862,12 +859,16 @@ __device__ __forceinline__ void copy_scene_to_lds(uint8_t* lds, const uint8_t* b
   __syncthreads();
 }
 
-enum : uint32_t { ST_TRAV = 0, ST_WAIT = 1, ST_DEAD = 2, ST_DONE = 3 };
+// A lane with a path is LIVE: it traverses while tv.cur != REF_EMPTY and waits to be shaded
+// once it is (every lane without a ray in flight holds REF_EMPTY there, so the traversal
+// loop tells the lanes apart by tv.cur alone).  DEAD: no path, wants one.  DONE: the
+// queue ran dry.
+enum : uint32_t { ST_LIVE = 0, ST_DEAD = 2, ST_DONE = 3 };
 
 // LDS of a render workgroup: [scene image (on-chip store only)][traversal stacks]
 // [per-wave tile sums]  (a lane pushes at most one entry per level of inner nodes above it)
 __host__ __device__ inline uint32_t stack_bytes(uint32_t threads, uint32_t depth, uint32_t wide) {
-  return (threads * (wide ? 4u : 2u) * (depth + 1u) + 15u) & ~15u;  // one slot above the deepest push
+  return (threads * (wide ? 4u : 2u) * (depth + 2u) + 15u) & ~15u;  // REF_EMPTY below, one slot above the deepest push
 }
 __host__ __device__ inline uint32_t image_bytes_in_lds(const SceneLayout& L) { return L.wide ? 0u : L.total_bytes; }
 constexpr uint32_t TILE_PIXELS = TILE_W * TILE_H;       // 64 = one wave
@@ -946,6 +947,8 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
   ray.o = ray.d = ray.inv = mk<R>((R)0, (R)0, (R)0);
   ray.a = ray.inv_a = ray.oo = (R)0;
   trav_begin<R, WIDE>(tv);
+  tv.cur = RF::EMPTY;
+  stack_lane[0] = (stack_t)RF::EMPTY;
 
   // adds the wave's tile sums to the frame and clears them
   auto flush_tile = [&]() {
@@ -967,7 +970,7 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
     // ---- 1. shade the finished rays: deposit, or prepare a scatter ------------------
     // A lane leaves this block as DEAD (path ended) or with `scatter` set.
     if (CNT) {
-      const uint64_t w = __ballot(state == ST_WAIT);
+      const uint64_t w = __ballot(state == ST_LIVE && tv.cur == RF::EMPTY);
       if (lane == 0 && w != 0ull) cnt.v[CTR_SHADE_ROUNDS]++;
     }
     bool scatter = false;
@@ -976,7 +979,7 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
     sf.param = (R)0;
     sf.mkind = 0u;
     sf.front = false;
-    if (state == ST_WAIT) {
+    if (state == ST_LIVE && tv.cur == RF::EMPTY) {
       Sink sink;
       sink.lds = tile_acc + pix * 3u;
       sink.global = frame + (size_t)pixel * 3u;
@@ -1069,7 +1072,7 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
         bounce++;
         ray_setup<R>(ray);
         ray_start<R, CNT, WIDE>(sc, ray, tv, t_min, cnt);
-        state = (tv.cur == RF::EMPTY) ? ST_WAIT : ST_TRAV;
+        state = ST_LIVE;
         if (CNT) cnt.v[CTR_RAYS]++;
       }  // else: absorbed, the lane stays DEAD and claims new work next round
     }
@@ -1084,41 +1087,39 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
     if (__ballot(state != ST_DONE) == 0ull) break;  // the queue is empty and every path ended
     // ---- 4. traversal: node steps while most lanes are at inner nodes, then one leaf
     //         step for the lanes that reached a primitive; until enough rays are done ----
-    while (__ballot(state == ST_TRAV) != 0ull) {
+    const int n_live = __popcll(__ballot(state == ST_LIVE));
+    while (__ballot(tv.cur != RF::EMPTY) != 0ull) {
       for (;;) {
-        const bool inner = state == ST_TRAV && !(tv.cur & RF::LEAF);
+        const bool inner = tv.cur < RF::LEAF;  // REF_EMPTY has the leaf bit set
         const uint64_t mi = __ballot(inner);
-        const uint64_t mt = __ballot(state == ST_TRAV);
+        const uint64_t mt = __ballot(tv.cur != RF::EMPTY);
         // leaves wait while at least 1/node_den of the travelling lanes still descend
         if (mi == 0ull || A.node_den * __popcll(mi) < __popcll(mt)) break;
         if (inner) {
           node_step<R, CNT, WIDE>(sc, ray, tv, stack_lane, t_min, cnt);
-          if (tv.cur == RF::EMPTY) state = ST_WAIT;
           if (CNT) cnt.v[CTR_ACTIVE]++;
         }
         if (CNT) cnt.v[CTR_STEPS]++;
         // a second step for the lanes that are still at inner nodes, without asking the
         // wave again: the ballots and counts of the loop head cost as much scalar issue
         // as half a node step
-        if (state == ST_TRAV && !(tv.cur & RF::LEAF)) {
+        if (tv.cur < RF::LEAF) {
           node_step<R, CNT, WIDE>(sc, ray, tv, stack_lane, t_min, cnt);
-          if (tv.cur == RF::EMPTY) state = ST_WAIT;
           if (CNT) cnt.v[CTR_ACTIVE]++;
         }
         if (CNT) cnt.v[CTR_STEPS]++;
       }
-      const bool leaf = state == ST_TRAV && (tv.cur & RF::LEAF);
+      const bool leaf = (uint32_t)(tv.cur - RF::LEAF) < (RF::EMPTY - RF::LEAF);
       if (__ballot(leaf) != 0ull) {
         if (leaf) {
           leaf_test<R, CNT, WIDE>(sc, ray, tv, tv.cur, t_min, cnt);
           tv.cur = trav_pop<R, WIDE>(tv, stack_lane);
-          if (tv.cur == RF::EMPTY) state = ST_WAIT;
           if (CNT) cnt.v[CTR_ACTIVE]++;
         }
         if (CNT) cnt.v[CTR_STEPS]++;
       }
       {
-        const int nw = __popcll(__ballot(state == ST_WAIT)), nt = __popcll(__ballot(state == ST_TRAV));
+        const int nt = __popcll(__ballot(tv.cur != RF::EMPTY)), nw = n_live - nt;
         if (nw >= A.wait_threshold || nw * A.wait_ratio_den >= nt * A.wait_ratio_num) break;
       }
     }
@@ -1162,6 +1163,7 @@ __global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, Cam
     lds_image = A.L.total_bytes;
   }
   stack_t* stack_lane = (stack_t*)(lds + lds_image) + threadIdx.x;
+  stack_lane[0] = (stack_t)RefT<WIDE>::EMPTY;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t tiles_x = (uint32_t)(A.W + TILE_W - 1) / TILE_W;
   const uint32_t tiles_y = (uint32_t)(A.H + TILE_H - 1) / TILE_H;
