@@ -312,6 +312,10 @@ int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_para
   a.jitter = p->jitter ? 1 : 0;
   a.seed_lo = (uint32_t)p->seed;
   a.seed_hi = (uint32_t)(p->seed >> 32);
+  for (uint32_t r = 0; r < 10; ++r) {
+    a.philox_keys[2 * r] = a.seed_lo + r * 0x9E3779B9u;
+    a.philox_keys[2 * r + 1] = a.seed_hi + r * 0xBB67AE85u;
+  }
   a.wait_threshold = g_wait_threshold.load();
   a.node_den = g_node_den.load();
   a.wait_ratio_num = g_wait_num.load();

@@ -30,6 +30,7 @@ struct RenderArgs {
   int32_t max_depth;
   int32_t jitter;
   uint32_t seed_lo, seed_hi;
+  uint32_t philox_keys[20];  // round keys of Philox4x32-10 for that seed: (lo + r*0x9E3779B9, hi + r*0xBB67AE85)
   int32_t wait_threshold;  // lanes that may wait for shading before traversal yields
   int32_t node_den;        // node steps go on while inner lanes * node_den >= travelling lanes
   int32_t wait_ratio_num, wait_ratio_den;  // traversal also yields when waiting/travelling >= num/den

@@ -115,7 +115,7 @@ template <typename R> __device__ __forceinline__ R dot(V3<R> a, V3<R> b) { retur
 template <typename R> __device__ __forceinline__ V3<R> cross(V3<R> a, V3<R> b) {
   return mk<R>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-template <typename R> __device__ __forceinline__ V3<R> ld3(const R* p) { return mk<R>(p[0], p[1], p[2]); }
+template <typename R, typename P> __device__ __forceinline__ V3<R> ld3(P p) { return mk<R>(p[0], p[1], p[2]); }
 
 // ---------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011)
@@ -133,6 +133,24 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// The same with the ten round keys (k0 + r*0x9E3779B9, k1 + r*0xBB67AE85) read from a table
+// the host prepared: kept as live values they would hold twenty scalar registers for the
+// whole kernel.
+template <typename KeyPtr>
+__device__ __forceinline__ void philox4x32_10_keyed(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                    KeyPtr keys, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ keys[2 * r];
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ keys[2 * r + 1];
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
@@ -827,9 +845,10 @@ __device__ __forceinline__ bool scatter_direction(const Surface<R>& sf, const Ra
 
 // Camera.get_ray (Camera.scala:19-23) for one sample of pixel (i, j)
 // (main.scala:88-89); rnd = the path's camera event.
-template <typename R>
-__device__ __forceinline__ void camera_ray(const RenderArgs& A, const CamDev<R>& cam, Ray<R>& ray,
+template <typename R, typename CamPtr>
+__device__ __forceinline__ void camera_ray(const RenderArgs& A, CamPtr camp, Ray<R>& ray,
                                            uint32_t i, uint32_t j, const uint32_t rnd[4]) {
+  const auto& cam = *camp;
   R xi1 = (R)0.5, xi2 = (R)0.5;
   V3<R> offset = mk<R>((R)0, (R)0, (R)0);
   if (A.jitter) {
@@ -846,6 +865,28 @@ __device__ __forceinline__ void camera_ray(const RenderArgs& A, const CamDev<R>&
   V3<R> origin = ld3<R>(cam.origin);
   ray.o = origin + offset;
   ray.d = ld3<R>(cam.llc) + s * ld3<R>(cam.horizontal) + t * ld3<R>(cam.vertical) - origin - offset;
+}
+
+// The camera of render_kernel, read from the kernel-argument segment where it is used.
+// Taken as an ordinary by-value parameter its 22 numbers sit in scalar registers for the
+// whole kernel, and the kernel is short of those: it spilled ~40 of them to vector lanes.
+// The empty asm hides the address from the optimiser, which would otherwise hoist the
+// loads back out of the main loop.
+template <typename R>
+__device__ __forceinline__ const __attribute__((address_space(4))) CamDev<R>* kernarg_camera() {
+  typedef const __attribute__((address_space(4))) char* kptr;
+  kptr p = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(RenderArgs);  // second parameter
+  asm volatile("" : "+s"(p));
+  return (const __attribute__((address_space(4))) CamDev<R>*)p;
+}
+
+// The arguments of render_kernel read the same way, for the values that only the rare
+// parts of the kernel use.
+__device__ __forceinline__ const __attribute__((address_space(4))) RenderArgs* kernarg_args() {
+  typedef const __attribute__((address_space(4))) char* kptr;
+  kptr p = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return (const __attribute__((address_space(4))) RenderArgs*)p;
 }
 
 // ---------------------------------------------------------------------------
@@ -883,7 +924,7 @@ constexpr uint32_t TILE_ACC_BYTES = TILE_PIXELS * 3u * 8u;
 // Waves per SIMD the register allocator must leave room for: the plain fp32 variants
 // are held to 80 VGPRs, so that 24 waves fit a CU next to the scene image.
 template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
-struct MinWaves { static constexpr int value = (sizeof(R) == 4 && !CNT && FEAT == 0u) ? 6 : 1; };
+struct MinWaves { static constexpr int value = (sizeof(R) == 4 && !CNT) ? (FEAT == 0u ? 6 : (FEAT == 3u ? 4 : 5)) : 1; };
 
 template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
 __global__ void __launch_bounds__(M<R>::BT) __attribute__((amdgpu_waves_per_eu(MinWaves<R, CNT, FEAT, WIDE>::value)))
@@ -919,7 +960,7 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
   const uint32_t n_small = (s_total - s_big + chunk_tail - 1u) / chunk_tail;
   const uint32_t n_units = n_tiles * (n_big + n_small);
   const R t_min = (R)0.001;  // Camera.scala:28
-  const V3<R> bg = ld3<R>(cam.background);
+  static_assert(sizeof(RenderArgs) % alignof(CamDev<R>) == 0, "camera follows RenderArgs without padding");
   Cnt cnt;
   uint64_t clk0 = 0, real0 = 0;
   if (CNT) {
@@ -986,6 +1027,8 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
       sink.current = my_epoch == epoch;
       state = ST_DEAD;
       if (tv.best_ref == RF::EMPTY) {
+        const auto* cp = kernarg_camera<R>();
+        const V3<R> bg = mk<R>(cp->background[0], cp->background[1], cp->background[2]);
         deposit<R>(sink, T * bg);  // case None => background (Camera.scala:34)
         if (CNT) cnt.v[CTR_MISS]++;
       } else if (shade_surface<R, CNT, FEAT, WIDE>(sc, A, ray, tv, T, sink, sf, cnt)) {
@@ -1057,10 +1100,10 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
     // (scatter event `bounce` of the path, or its camera event 0)
     if (scatter || camera) {
       uint32_t rnd[4];
-      philox4x32_10(pixel, sample, bounce, 0u, A.seed_lo, A.seed_hi, rnd);
+      philox4x32_10_keyed(pixel, sample, bounce, 0u, kernarg_args()->philox_keys, rnd);
       bool go = true;
       if (camera) {
-        camera_ray<R>(A, cam, ray, cpx, cpy, rnd);
+        camera_ray<R>(A, kernarg_camera<R>(), ray, cpx, cpy, rnd);
         T = mk<R>((R)1, (R)1, (R)1);
       } else {
         V3<R> dir;
@@ -1180,7 +1223,7 @@ __global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, Cam
   ra.H = A.H;
   const uint32_t no_rnd[4] = {0u, 0u, 0u, 0u};
   Ray<R> ray;
-  camera_ray<R>(ra, cam, ray, px, py, no_rnd);  // jitter off: pixel centre, lens closed
+  camera_ray<R>(ra, &cam, ray, px, py, no_rnd);  // jitter off: pixel centre, lens closed
   ray_setup<R>(ray);
   Trav<R> tv;
   trace_closest<R, WIDE>(sc, ray, tv, stack_lane, (R)0.001);
