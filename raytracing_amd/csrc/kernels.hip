@@ -255,15 +255,15 @@ __device__ __forceinline__ void ray_setup(Ray<R>& r) {
 template <typename R>
 struct Trav {
   uint32_t cur;       // reference being processed; REF_EMPTY when the ray is finished
-  uint32_t sp;        // stack elements in use, the REF_EMPTY at the bottom included: level * blockDim.x
+  uint32_t sp;        // LDS byte address of the lane's next free stack slot (layout [level][thread])
   uint32_t best_ref;  // REF_EMPTY = no hit yet
   R best_t;
 };
 
 template <typename R, bool WIDE>
-__device__ __forceinline__ void trav_begin(Trav<R>& tv) {
+__device__ __forceinline__ void trav_begin(Trav<R>& tv, uint32_t stack_level1) {
   tv.cur = 0;  // root is inner node 0
-  tv.sp = blockDim.x;  // level 0 of every lane's stack holds REF_EMPTY for good
+  tv.sp = stack_level1;  // level 0 of every lane's stack holds REF_EMPTY for good
   tv.best_ref = RefT<WIDE>::EMPTY;
   tv.best_t = M<R>::inf();
 }
@@ -482,20 +482,22 @@ __device__ __forceinline__ void leaf_test(const Scene& sc, const Ray<R>& ray, Tr
 // issues at half the rate of an add, and the loop is also short of scalar issue, so both
 // operations are free of branches.
 template <typename R, bool WIDE>
-__device__ __forceinline__ uint32_t trav_pop(Trav<R>& tv, const typename RefT<WIDE>::stack_t* stack_lane) {
-  tv.sp -= blockDim.x;  // stack layout is [level][thread]; sp counts elements, not levels
-  return (uint32_t)stack_lane[tv.sp];
+__device__ __forceinline__ uint32_t trav_pop(Trav<R>& tv, const uint8_t* lds) {
+  typedef typename RefT<WIDE>::stack_t stack_t;
+  tv.sp -= blockDim.x * (uint32_t)sizeof(stack_t);  // one level down
+  return (uint32_t)*(const stack_t*)(lds + tv.sp);
 }
 
 // Inner node: slab-test both children, descend into the nearer one that is hit
 // and push the other, or pop when neither is.
 template <typename R, bool CNT, bool WIDE>
 __device__ __forceinline__ void node_step(const Scene& sc, const Ray<R>& ray, Trav<R>& tv,
-                                          typename RefT<WIDE>::stack_t* stack_lane, R t_min, Cnt& cnt) {
-  const uint32_t BT = blockDim.x;
+                                          uint8_t* lds, R t_min, Cnt& cnt) {
+  typedef typename RefT<WIDE>::stack_t stack_t;
+  const uint32_t LEVEL = blockDim.x * (uint32_t)sizeof(stack_t);
   // what a pop would return, read before the arithmetic so that its latency hides there
-  const uint32_t below = tv.sp - BT;
-  const uint32_t top = (uint32_t)stack_lane[below];
+  const uint32_t below = tv.sp - LEVEL;
+  const uint32_t top = (uint32_t)*(const stack_t*)(lds + below);
   R b[12];
   uint32_t c0, c1;
   load_node<WIDE>(sc, tv.cur, b, c0, c1);
@@ -507,17 +509,17 @@ __device__ __forceinline__ void node_step(const Scene& sc, const Ray<R>& ray, Tr
   const bool swp = tn1 < tn0;                         // meaningful when both are hit
   const uint32_t farc = swp ? c0 : c1;
   const uint32_t nearc = both ? (swp ? c1 : c0) : (h0 ? c0 : c1);
-  stack_lane[tv.sp] = (typename RefT<WIDE>::stack_t)farc;  // kept only if the count moves past it
+  *(stack_t*)(lds + tv.sp) = (stack_t)farc;  // kept only if the address moves past it
   tv.cur = none ? top : nearc;
-  tv.sp = both ? tv.sp + BT : (none ? below : tv.sp);
+  tv.sp = both ? tv.sp + LEVEL : (none ? below : tv.sp);
 }
 
 // Start of a ray: the hoisted primitives (the same primitive for every lane, so
 // the wave runs one code path), then the bounds of the hierarchy.
 template <typename R, bool CNT, bool WIDE>
-__device__ __forceinline__ void ray_start(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, R t_min,
-                                          Cnt& cnt) {
-  trav_begin<R, WIDE>(tv);
+__device__ __forceinline__ void ray_start(const Scene& sc, const Ray<R>& ray, Trav<R>& tv,
+                                          uint32_t stack_level1, R t_min, Cnt& cnt) {
+  trav_begin<R, WIDE>(tv, stack_level1);
   const uint32_t* hl = (const uint32_t*)(sc.base + sc.L.hoist);
   for (uint32_t i = 0; i < sc.L.n_hoist; ++i) {
     const uint32_t ref = __builtin_amdgcn_readfirstlane(hl[i]);
@@ -535,15 +537,15 @@ __device__ __forceinline__ void ray_start(const Scene& sc, const Ray<R>& ray, Tr
 // The whole closest-hit query of one lane (first-hit kernel).
 template <typename R, bool WIDE>
 __device__ __forceinline__ void trace_closest(const Scene& sc, const Ray<R>& ray, Trav<R>& tv,
-                                              typename RefT<WIDE>::stack_t* stack_lane, R t_min) {
+                                              uint8_t* lds, uint32_t stack_level1, R t_min) {
   Cnt cnt;
-  ray_start<R, false, WIDE>(sc, ray, tv, t_min, cnt);
+  ray_start<R, false, WIDE>(sc, ray, tv, stack_level1, t_min, cnt);
   while (tv.cur != RefT<WIDE>::EMPTY) {
     if (!(tv.cur & RefT<WIDE>::LEAF)) {
-      node_step<R, false, WIDE>(sc, ray, tv, stack_lane, t_min, cnt);
+      node_step<R, false, WIDE>(sc, ray, tv, lds, t_min, cnt);
     } else {
       prim_test<R, false, WIDE>(sc, ray, tv, tv.cur, t_min, cnt);
-      tv.cur = trav_pop<R, WIDE>(tv, stack_lane);
+      tv.cur = trav_pop<R, WIDE>(tv, lds);
     }
   }
 }
@@ -571,20 +573,24 @@ __device__ __forceinline__ HitGeom<R> hit_geometry(const Scene& sc, const Ray<R>
     // half-chord, both of the size of the radius, so its error scales with the
     // radius and not with the distance the ray travelled; the hit point is then
     // center + that vector.
-    SphereSolve<R> ss;
-    sphere_solve<R>(sc, ray, h.kind, h.idx, ss);
     V3<R> pc;
-    if (ss.big) {
-      pc = h.p - ss.cen;
+    R rad;
+    if (h.kind == KIND_BIG_SPHERE) {  // the hit point is as accurate as the radius is large
+      typename M<R>::R4 s = load_r4<R>(sc, sc.L.sph, h.idx);
+      pc = h.p - mk<R>(s.x, s.y, s.z);
+      rad = s.w;
     } else {
+      SphereSolve<R> ss;
+      sphere_solve<R>(sc, ray, KIND_SPHERE, h.idx, ss);
       // one re-orthogonalisation of l against d removes the along-ray error that the
       // rounding of the closest-approach parameter left in it
       const V3<R> l = ss.l - (dot(ss.l, ray.d) * ray.inv_a) * ray.d;
       const bool near_root = M<R>::fabs(t - ss.t1) <= M<R>::fabs(t - ss.t2);
       pc = l + (near_root ? -ss.s : ss.s) * ray.d;
       h.p = ss.cen + pc;
+      rad = ss.rad;
     }
-    h.n_out = M<R>::rcp(ss.rad) * pc;
+    h.n_out = M<R>::rcp(rad) * pc;
     h.meta = load_u32(sc, sc.L.meta_sph, h.idx);
   } else if (h.kind == KIND_TRIANGLE) {
     typename M<R>::R4 q2 = load_r4<R>(sc, sc.L.tri, h.idx * 3u + 2u);
@@ -860,6 +866,8 @@ __device__ __forceinline__ void camera_ray(const RenderArgs& A, CamPtr camp, Ray
     M<R>::sincos2pi(u01<R>(rnd[3]), s, c);
     offset = (r * c) * ld3<R>(cam.u) + (r * s) * ld3<R>(cam.v);
   }
+  // a true division, as main.scala:88-89 has it: a reciprocal and a multiply would save
+  // ~30 instructions per camera ray, and move pixel-centre rays across texel boundaries
   R s = ((R)i + xi1) / (R)(A.W - 1);
   R t = ((R)j + xi2) / (R)(A.H - 1);
   V3<R> origin = ld3<R>(cam.origin);
@@ -943,7 +951,9 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
     sc.base = lds;
     lds_image = A.L.total_bytes;
   }
-  stack_t* stack_lane = (stack_t*)(lds + lds_image) + threadIdx.x;
+  // the lane's stack: level 0 (holds REF_EMPTY) and level 1, as byte offsets into lds
+  const uint32_t stack_level0 = lds_image + threadIdx.x * (uint32_t)sizeof(stack_t);
+  const uint32_t stack_level1 = stack_level0 + BT * (uint32_t)sizeof(stack_t);
   const uint32_t lane = threadIdx.x & 63u;
   unsigned long long* tile_acc = (unsigned long long*)(lds + lds_image + stack_bytes(BT, A.L.depth, WIDE ? 1u : 0u) +
                                                        (threadIdx.x >> 6) * TILE_ACC_BYTES);
@@ -987,9 +997,9 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
   uint32_t my_epoch = 0, pix = 0, pixel = 0, sample = 0, bounce = 0;
   ray.o = ray.d = ray.inv = mk<R>((R)0, (R)0, (R)0);
   ray.a = ray.inv_a = ray.oo = (R)0;
-  trav_begin<R, WIDE>(tv);
+  trav_begin<R, WIDE>(tv, stack_level1);
   tv.cur = RF::EMPTY;
-  stack_lane[0] = (stack_t)RF::EMPTY;
+  *(stack_t*)(lds + stack_level0) = (stack_t)RF::EMPTY;
 
   // adds the wave's tile sums to the frame and clears them
   auto flush_tile = [&]() {
@@ -1114,7 +1124,7 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
       if (go) {
         bounce++;
         ray_setup<R>(ray);
-        ray_start<R, CNT, WIDE>(sc, ray, tv, t_min, cnt);
+        ray_start<R, CNT, WIDE>(sc, ray, tv, stack_level1, t_min, cnt);
         state = ST_LIVE;
         if (CNT) cnt.v[CTR_RAYS]++;
       }  // else: absorbed, the lane stays DEAD and claims new work next round
@@ -1139,7 +1149,7 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
         // leaves wait while at least 1/node_den of the travelling lanes still descend
         if (mi == 0ull || A.node_den * __popcll(mi) < __popcll(mt)) break;
         if (inner) {
-          node_step<R, CNT, WIDE>(sc, ray, tv, stack_lane, t_min, cnt);
+          node_step<R, CNT, WIDE>(sc, ray, tv, lds, t_min, cnt);
           if (CNT) cnt.v[CTR_ACTIVE]++;
         }
         if (CNT) cnt.v[CTR_STEPS]++;
@@ -1147,7 +1157,7 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
         // wave again: the ballots and counts of the loop head cost as much scalar issue
         // as half a node step
         if (tv.cur < RF::LEAF) {
-          node_step<R, CNT, WIDE>(sc, ray, tv, stack_lane, t_min, cnt);
+          node_step<R, CNT, WIDE>(sc, ray, tv, lds, t_min, cnt);
           if (CNT) cnt.v[CTR_ACTIVE]++;
         }
         if (CNT) cnt.v[CTR_STEPS]++;
@@ -1156,7 +1166,7 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
       if (__ballot(leaf) != 0ull) {
         if (leaf) {
           leaf_test<R, CNT, WIDE>(sc, ray, tv, tv.cur, t_min, cnt);
-          tv.cur = trav_pop<R, WIDE>(tv, stack_lane);
+          tv.cur = trav_pop<R, WIDE>(tv, lds);
           if (CNT) cnt.v[CTR_ACTIVE]++;
         }
         if (CNT) cnt.v[CTR_STEPS]++;
@@ -1205,8 +1215,8 @@ __global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, Cam
     sc.base = lds;
     lds_image = A.L.total_bytes;
   }
-  stack_t* stack_lane = (stack_t*)(lds + lds_image) + threadIdx.x;
-  stack_lane[0] = (stack_t)RefT<WIDE>::EMPTY;
+  const uint32_t stack_level0 = lds_image + threadIdx.x * (uint32_t)sizeof(stack_t);
+  *(stack_t*)(lds + stack_level0) = (stack_t)RefT<WIDE>::EMPTY;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t tiles_x = (uint32_t)(A.W + TILE_W - 1) / TILE_W;
   const uint32_t tiles_y = (uint32_t)(A.H + TILE_H - 1) / TILE_H;
@@ -1226,7 +1236,7 @@ __global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, Cam
   camera_ray<R>(ra, &cam, ray, px, py, no_rnd);  // jitter off: pixel centre, lens closed
   ray_setup<R>(ray);
   Trav<R> tv;
-  trace_closest<R, WIDE>(sc, ray, tv, stack_lane, (R)0.001);
+  trace_closest<R, WIDE>(sc, ray, tv, lds, stack_level0 + BT * (uint32_t)sizeof(stack_t), (R)0.001);
 
   R* t_out = (R*)A.t;
   R* n_out = (R*)A.normal;
