@@ -188,7 +188,7 @@ def main():
         # roofline of the dominant kernel (render_kernel<float>) on this rank
         ksec = sum(k for k, _ in kernel_s)
         launches = sum(n for _, n in kernel_s)
-        cparams = ht.make_params(W, H, min(16, max(count, 1)), sample_offset=first, seed=2025,
+        cparams = ht.make_params(W, H, min(64, max(count, 1)), sample_offset=first, seed=2025,
                                  device=local_rank, collect_counters=1)
         accum.zero_()
         ctr = scene.render_accumulate(cam, cparams, accum.data_ptr(), stream, want_stats=True)
