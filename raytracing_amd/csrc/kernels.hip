@@ -1063,7 +1063,9 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
         if (epoch != 0u) flush_tile();
         uint32_t unit = 0;
         if (lane == 0) unit = atomicAdd(A.tile_counter, 1u);
-        unit = __shfl(unit, 0);
+        // every lane is here (the loop's control is wave-uniform); read as a scalar, so that
+        // the unit's state lives in scalar registers and the loop branches on scalars
+        unit = __builtin_amdgcn_readfirstlane(unit);
         if (unit >= n_units) {
           queue_empty = true;
           epoch++;  // whatever is still in flight deposits to the frame directly
