@@ -958,17 +958,6 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
   unsigned long long* tile_acc = (unsigned long long*)(lds + lds_image + stack_bytes(BT, A.L.depth, WIDE ? 1u : 0u) +
                                                        (threadIdx.x >> 6) * TILE_ACC_BYTES);
   unsigned long long* frame = (unsigned long long*)A.accum;
-  const uint32_t tiles_x = (uint32_t)(A.W + TILE_W - 1) / TILE_W;
-  const uint32_t tiles_y = (uint32_t)(A.H + TILE_H - 1) / TILE_H;
-  const uint32_t n_tiles = tiles_x * tiles_y;
-  // the last `chunk` samples of the launch are cut into units of `chunk_tail` samples:
-  // the units still running when the queue runs dry decide how long the launch drags on
-  const uint32_t chunk = (uint32_t)A.chunk, chunk_tail = (uint32_t)A.chunk_tail;
-  const uint32_t s_total = (uint32_t)A.sample_count;
-  const uint32_t s_big = s_total > chunk ? s_total - chunk : 0u;        // samples in full-size units
-  const uint32_t n_big = (s_big + chunk - 1u) / chunk;
-  const uint32_t n_small = (s_total - s_big + chunk_tail - 1u) / chunk_tail;
-  const uint32_t n_units = n_tiles * (n_big + n_small);
   const R t_min = (R)0.001;  // Camera.scala:28
   static_assert(sizeof(RenderArgs) % alignof(CamDev<R>) == 0, "camera follows RenderArgs without padding");
   Cnt cnt;
@@ -1061,8 +1050,22 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
           break;
         }
         if (epoch != 0u) flush_tile();
+        // The queue's geometry is worked out here, once per unit, from arguments read on
+        // the spot: as values kept over the whole kernel it held ten scalar registers.
+        const auto* ca = kernarg_args();
+        const uint32_t tiles_x = (uint32_t)(ca->W + TILE_W - 1) / TILE_W;
+        const uint32_t tiles_y = (uint32_t)(ca->H + TILE_H - 1) / TILE_H;
+        const uint32_t n_tiles = tiles_x * tiles_y;
+        // the last `chunk` samples of the launch are cut into units of `chunk_tail` samples:
+        // the units still running when the queue runs dry decide how long the launch drags on
+        const uint32_t chunk = (uint32_t)ca->chunk, chunk_tail = (uint32_t)ca->chunk_tail;
+        const uint32_t s_total = (uint32_t)ca->sample_count;
+        const uint32_t s_big = s_total > chunk ? s_total - chunk : 0u;        // samples in full-size units
+        const uint32_t n_big = (s_big + chunk - 1u) / chunk;
+        const uint32_t n_small = (s_total - s_big + chunk_tail - 1u) / chunk_tail;
+        const uint32_t n_units = n_tiles * (n_big + n_small);
         uint32_t unit = 0;
-        if (lane == 0) unit = atomicAdd(A.tile_counter, 1u);
+        if (lane == 0) unit = atomicAdd(ca->tile_counter, 1u);
         // every lane is here (the loop's control is wave-uniform); read as a scalar, so that
         // the unit's state lives in scalar registers and the loop branches on scalars
         unit = __builtin_amdgcn_readfirstlane(unit);
@@ -1082,7 +1085,7 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
           first = s_big + (ck - n_big) * chunk_tail;
           count = min(chunk_tail, s_total - first);
         }
-        sample_base = (uint32_t)A.sample_first + first;
+        sample_base = (uint32_t)ca->sample_first + first;
         pool_size = TILE_PIXELS * count;
         next_item = 0;
         epoch++;
