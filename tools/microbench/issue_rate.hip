@@ -136,6 +136,12 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (argc > 1 && argv[1][0] == 'k') {  // how many active lanes it takes to leave the slow mode
+    static char nm[64][16];
+    for (int k = 1; k <= 20; ++k) { snprintf(nm[k], 16, "%d low", k); run_kind<K_FMA>(d_out, 4, (1ull << k) - 1ull, nm[k], 2); }
+    for (int k = 1; k <= 8; ++k) { snprintf(nm[20 + k], 16, "%d spread", k); uint64_t m = 0; for (int j = 0; j < k; ++j) m |= 1ull << (j * 8); run_kind<K_MAX>(d_out, 4, m, nm[20 + k], 2); }
+    return 0;
+  }
   if (argc > 1) {  // exec-mask scan
     mask_scan<K_FMA>(d_out); mask_scan<K_MUL>(d_out); mask_scan<K_ADD>(d_out); mask_scan<K_MAX>(d_out);
     mask_scan<K_MIN3>(d_out); mask_scan<K_PKADD>(d_out); mask_scan<K_AND>(d_out); mask_scan<K_CNDMASK>(d_out);
