@@ -171,3 +171,32 @@ def test_axis_parallel_rays(dev, oracle_mod):
             assert (fh["prim_id"] != ofh["prim_id"]).mean() < 0.01
             assert np.abs(g64["rgb"] - o["rgb"]).max() <= 3e-6
         assert len(np.unique(ofh["prim_id"][H // 2, :])) >= 3  # the middle row sees several objects
+
+
+def test_scene_far_from_the_origin(dev, oracle_mod):
+    """Boxes whose centre is large against their half-extent (the fp32 nodes store both):
+    the whole scene and the camera moved 6000 units away.  The fp64 path still equals the
+    oracle; the fp32 path sees what fp32 coordinates allow, the same in both scene stores."""
+    from raytracing_amd.meshgen import bumpy_ellipsoid
+    from raytracing_amd.scene import Mesh
+    off = np.array([3000.0, -2000.0, 5000.0])
+    grey = Diffuse(SolidColor((0.7, 0.7, 0.7)))
+    world = [Sphere(tuple(np.array([0.0, -1001.5, 0.0]) + off), 1000.0, grey), Mesh(bumpy_ellipsoid(16, 32) + off, grey)]
+    world += [Sphere(tuple(np.array([0.6 * i - 2.4, 0.3, 1.8]) + off), 0.25, grey) for i in range(9)]
+    flat = flatten(world)
+    cam = Camera(tuple(np.array([2.0, 2.0, 7.0]) + off), tuple(off), (0.0, 1.0, 0.0), 35.0, 1.5, 0.0, -1.0, (0.5, 0.7, 1.0))
+    W, H = 120, 80
+    ofh = oracle_mod.OracleScene(flat).first_hit(cam, W, H)
+    got = []
+    for hbm in (0, 1):
+        dev.set_option("force_hbm_scene", hbm)
+        try:
+            with dev.Scene(flat, device=0) as s:
+                fh64 = s.first_hit(cam, W, H, precision=A.HT_PRECISION_FP64)
+                got.append(s.first_hit(cam, W, H)["prim_id"])
+        finally:
+            dev.set_option("force_hbm_scene", 0)
+        assert np.array_equal(fh64["prim_id"], ofh["prim_id"])
+    assert np.array_equal(got[0], got[1])                      # the two stores agree in fp32
+    assert (got[0] != ofh["prim_id"]).mean() < 0.03            # fp32 coordinates at 6000: silhouettes only
+    assert len(np.unique(ofh["prim_id"])) > 50
