@@ -268,6 +268,7 @@ int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_para
   const int prec = p->precision;
   const bool counters = p->collect_counters != 0;
   const SceneLayout& L = prec == HT_PRECISION_FP32 ? s->hs.layout32 : s->hs.layout64;
+  const uint32_t kfeat = s->feat | (L.tree_kinds == TREE_TRIANGLES ? KFEAT_TRIS : 0u);
   // workgroup size and count: the combination that keeps the most waves resident per CU;
   // smaller groups win ties (measured on the Cornell box, 32 waves per CU either way:
   // 256 x 8 34.2, 512 x 4 32.8, 1024 x 2 27.7 G samples/s)
@@ -277,7 +278,7 @@ int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_para
   for (int t = 256; t <= (int)max_block_threads(prec); t += 128) {
     if (forced > 0 && t != forced) continue;
     const uint32_t need = lds_bytes_needed(L, (uint32_t)t);
-    int b = render_blocks_per_cu(prec, counters, s->feat, L.wide != 0u, t, need);
+    int b = render_blocks_per_cu(prec, counters, kfeat, L.wide != 0u, t, need);
     b = std::min(b, g_max_blocks_per_cu.load());
     // several workgroups share a CU well only when each fills the four SIMDs evenly: two
     // groups of 14 waves (measured on the Cornell box) ran 20 % slower than two of 12
@@ -361,7 +362,7 @@ int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_para
     a.sample_first = p->sample_offset + done;
     a.sample_count = std::min(batch, p->samples - done);
     e = hipMemsetAsync(s->d_tile_counter, 0, 256, stream);
-    if (e == hipSuccess) e = launch_render(prec, counters, s->feat, a, camp, grid, threads, lds, stream);
+    if (e == hipSuccess) e = launch_render(prec, counters, kfeat, a, camp, grid, threads, lds, stream);
     if (e == hipSuccess) e = hipEventRecord(ev_batch[launches & 1], stream);
     launches++;
   }

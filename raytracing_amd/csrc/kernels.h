@@ -64,6 +64,7 @@ uint32_t max_block_threads(int precision);
 
 // texture features a kernel variant is built for
 constexpr uint32_t KFEAT_PERLIN = 1u, KFEAT_IMAGE = 2u;
+constexpr uint32_t KFEAT_TRIS = 4u;  // the hierarchy holds triangles only (used when no texture bit is set)
 
 // Number of workgroups of `threads` threads per CU the device can hold for this
 // kernel variant and LDS size (0: does not fit).

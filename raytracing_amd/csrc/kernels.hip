@@ -462,11 +462,11 @@ __device__ __forceinline__ void prim_test(const Scene& sc, const Ray<R>& ray, Tr
 // A leaf of the hierarchy.  The host records which kinds of primitive the hierarchy
 // holds (SceneLayout::tree_kinds, wave-uniform): a mesh or a field of spheres skips the
 // dispatch on the kind altogether.
-template <typename R, bool CNT, bool WIDE>
+template <typename R, bool CNT, bool WIDE, bool TRIS>
 __device__ __forceinline__ void leaf_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t ref,
                                           R t_min, Cnt& cnt) {
   const uint32_t idx = ref & RefT<WIDE>::INDEX_MASK;
-  if (sc.L.tree_kinds == TREE_TRIANGLES) triangle_test<R, CNT>(sc, ray, tv, ref, idx, t_min, cnt);
+  if (TRIS || sc.L.tree_kinds == TREE_TRIANGLES) triangle_test<R, CNT>(sc, ray, tv, ref, idx, t_min, cnt);
   else if (sc.L.tree_kinds == TREE_SPHERES) sphere_test<R, CNT>(sc, ray, tv, ref, KIND_SPHERE, idx, t_min, cnt);
   else prim_test<R, CNT, WIDE>(sc, ray, tv, ref, t_min, cnt);
 }
@@ -680,6 +680,9 @@ __device__ __forceinline__ R perlin_turb(const Scene& sc, uint32_t table, V3<R> 
 // FEAT: which texture kinds beyond SolidColor / Checker the scene uses; the others
 // are compiled out (the Perlin and Image paths alone cost ~50 VGPRs).
 constexpr uint32_t FEAT_PERLIN = 1u, FEAT_IMAGE = 2u;
+// Not a texture kind: the hierarchy holds triangles only (a mesh scene), known when the
+// kernel is compiled, so a leaf step has no dispatch on the kind of primitive at all.
+constexpr uint32_t FEAT_TRIS = 4u;
 
 template <typename R, bool CNT, uint32_t FEAT>
 __device__ __forceinline__ V3<R> texture_eval(const Scene& sc, const uint32_t* __restrict__ texels,
@@ -932,7 +935,7 @@ constexpr uint32_t TILE_ACC_BYTES = TILE_PIXELS * 3u * 8u;
 // Waves per SIMD the register allocator must leave room for: the plain fp32 variants
 // are held to 80 VGPRs, so that 24 waves fit a CU next to the scene image.
 template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
-struct MinWaves { static constexpr int value = (sizeof(R) == 4 && !CNT) ? (FEAT == 0u ? 6 : (FEAT == 3u ? 4 : 5)) : 1; };
+struct MinWaves { static constexpr int value = (sizeof(R) == 4 && !CNT) ? ((FEAT & 3u) == 0u ? 6 : ((FEAT & 3u) == 3u ? 4 : 5)) : 1; };
 
 template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
 __global__ void __launch_bounds__(M<R>::BT) __attribute__((amdgpu_waves_per_eu(MinWaves<R, CNT, FEAT, WIDE>::value)))
@@ -1170,7 +1173,7 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
       const bool leaf = (uint32_t)(tv.cur - RF::LEAF) < (RF::EMPTY - RF::LEAF);
       if (__ballot(leaf) != 0ull) {
         if (leaf) {
-          leaf_test<R, CNT, WIDE>(sc, ray, tv, tv.cur, t_min, cnt);
+          leaf_test<R, CNT, WIDE, (FEAT & FEAT_TRIS) != 0u>(sc, ray, tv, tv.cur, t_min, cnt);
           tv.cur = trav_pop<R, WIDE>(tv, lds);
           if (CNT) cnt.v[CTR_ACTIVE]++;
         }
@@ -1303,20 +1306,25 @@ static hipError_t allow_big_lds(K kernel, uint32_t lds_bytes) {
 }
 
 namespace {
+// KFEAT_* bits -> column of the kernel tables
+inline uint32_t feat_index(uint32_t feat) { return (feat & 3u) == 0u && (feat & FEAT_TRIS) ? 4u : (feat & 3u); }
 typedef void (*RenderKernel32)(RenderArgs, CamDev<float>);
 typedef void (*RenderKernel64)(RenderArgs, CamDev<double>);
+// the fifth entry: plain textures and a triangle-only hierarchy (fp32 production variant only;
+// elsewhere the generic kernel stands in)
 #define HT_FEAT_ROW(R, CNT, WIDE)                                                              \
   {render_kernel<R, CNT, 0, WIDE>, render_kernel<R, CNT, 1, WIDE>, render_kernel<R, CNT, 2, WIDE>, \
-   render_kernel<R, CNT, 3, WIDE>}
+   render_kernel<R, CNT, 3, WIDE>,                                                             \
+   render_kernel<R, CNT, (sizeof(R) == 4 && !CNT) ? FEAT_TRIS : 0u, WIDE>}
 // [store][counters][feat]
-const RenderKernel32 k32[2][2][4] = {{HT_FEAT_ROW(float, false, false), HT_FEAT_ROW(float, true, false)},
+const RenderKernel32 k32[2][2][5] = {{HT_FEAT_ROW(float, false, false), HT_FEAT_ROW(float, true, false)},
                                      {HT_FEAT_ROW(float, false, true), HT_FEAT_ROW(float, true, true)}};
-const RenderKernel64 k64[2][2][4] = {{HT_FEAT_ROW(double, false, false), HT_FEAT_ROW(double, true, false)},
+const RenderKernel64 k64[2][2][5] = {{HT_FEAT_ROW(double, false, false), HT_FEAT_ROW(double, true, false)},
                                      {HT_FEAT_ROW(double, false, true), HT_FEAT_ROW(double, true, true)}};
 #undef HT_FEAT_ROW
 const void* render_kernel_ptr(int precision, bool counters, uint32_t feat, bool wide) {
-  return precision == 0 ? reinterpret_cast<const void*>(k32[wide ? 1 : 0][counters ? 1 : 0][feat & 3u])
-                        : reinterpret_cast<const void*>(k64[wide ? 1 : 0][counters ? 1 : 0][feat & 3u]);
+  return precision == 0 ? reinterpret_cast<const void*>(k32[wide ? 1 : 0][counters ? 1 : 0][feat_index(feat)])
+                        : reinterpret_cast<const void*>(k64[wide ? 1 : 0][counters ? 1 : 0][feat_index(feat)]);
 }
 }  // namespace
 
@@ -1339,10 +1347,10 @@ hipError_t launch_render(int precision, bool counters, uint32_t feat, const Rend
                          int grid_blocks, int threads, uint32_t lds_bytes, hipStream_t stream) {
   const int w = a.L.wide ? 1 : 0;
   if (precision == 0) {
-    hipLaunchKernelGGL(k32[w][counters ? 1 : 0][feat & 3u], dim3(grid_blocks), dim3(threads), lds_bytes, stream,
+    hipLaunchKernelGGL(k32[w][counters ? 1 : 0][feat_index(feat)], dim3(grid_blocks), dim3(threads), lds_bytes, stream,
                        a, *static_cast<const CamDev<float>*>(cam));
   } else {
-    hipLaunchKernelGGL(k64[w][counters ? 1 : 0][feat & 3u], dim3(grid_blocks), dim3(threads), lds_bytes, stream,
+    hipLaunchKernelGGL(k64[w][counters ? 1 : 0][feat_index(feat)], dim3(grid_blocks), dim3(threads), lds_bytes, stream,
                        a, *static_cast<const CamDev<double>*>(cam));
   }
   return hipGetLastError();
