@@ -11,6 +11,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -22,6 +23,17 @@
 
 using namespace ht;
 
+// Launch shape of the render kernel for one (precision, counters) variant of a scene.
+struct LaunchShape {
+  int threads = 0, bpc = 0;
+  uint32_t lds = 0;
+  int generation = -1;  // option generation it was worked out under
+};
+
+// Work-queue heads: every launch takes the next one of a ring, so launches of one scene
+// handle may overlap on different streams (up to QUEUE_SLOTS of them in flight).
+constexpr uint32_t QUEUE_SLOTS = 64, QUEUE_SLOT_BYTES = 256;
+
 struct ht_scene {
   HostScene hs;
   int device = 0;
@@ -29,10 +41,13 @@ struct ht_scene {
   uint8_t* d_blob32 = nullptr;
   uint8_t* d_blob64 = nullptr;
   uint32_t* d_texels = nullptr;
-  uint32_t* d_tile_counter = nullptr;
+  uint8_t* d_queue_heads = nullptr;  // QUEUE_SLOTS heads, QUEUE_SLOT_BYTES apart
+  std::atomic<uint32_t> next_head{0};
   unsigned long long* d_counters = nullptr;
   std::atomic<int> cancel{0};
   uint32_t feat = 0;  // KFEAT_* texture kinds present in the scene
+  std::mutex shape_mutex;
+  LaunchShape shape[2][2];  // [precision][counters]
 };
 
 struct ht_frame {
@@ -44,15 +59,15 @@ struct ht_frame {
 
 namespace {
 
-thread_local std::string g_error;
+// The calling thread's last error message: a fixed buffer, so that reporting an error
+// allocates nothing.
+thread_local char g_error[512] = "";
 
 int fail(int code, const char* fmt, ...) {
-  char buf[512];
   va_list ap;
   va_start(ap, fmt);
-  vsnprintf(buf, sizeof buf, fmt, ap);
+  vsnprintf(g_error, sizeof g_error, fmt, ap);
   va_end(ap);
-  g_error = buf;
   return code;
 }
 
@@ -66,6 +81,21 @@ int fail(int code, const char* fmt, ...) {
     }                                                                                         \
   } while (0)
 
+// No C++ exception leaves an entry point: every body that can allocate host memory or
+// start a thread runs inside these.
+#define HT_API_TRY try {
+#define HT_API_CATCH                                                         \
+  }                                                                          \
+  catch (const std::bad_alloc&) {                                            \
+    return fail(HT_E_INVALID, "out of host memory");                         \
+  }                                                                          \
+  catch (const std::exception& ex) {                                         \
+    return fail(HT_E_INVALID, "internal error: %s", ex.what());              \
+  }                                                                          \
+  catch (...) {                                                              \
+    return fail(HT_E_INVALID, "internal error: unknown exception");          \
+  }
+
 // tuning knobs (ht_set_option)
 std::atomic<int> g_wait_threshold{40};
 std::atomic<int> g_max_blocks_per_cu{8};
@@ -74,7 +104,8 @@ std::atomic<int> g_node_den{2}, g_wait_num{1000}, g_wait_den{1};
 std::atomic<int> g_default_batch{1024};
 std::atomic<int> g_chunk{8};
 std::atomic<int> g_chunk_tail{4};
-std::atomic<int> g_force_hbm{0};  // scenes created while set keep their image in HBM
+std::atomic<int> g_force_hbm{0};     // scenes created while set keep their image in HBM
+std::atomic<int> g_shape_generation{0};  // bumped by the options a launch shape depends on
 
 // Makes `device` current for the lifetime of the object, then restores.
 struct DeviceGuard {
@@ -115,6 +146,240 @@ int check_camera(const ht_camera* cam) {
   return HT_OK;
 }
 
+int check_params(const ht_scene* s, const ht_render_params* p) {
+  if (p->width < 2 || p->height < 2)
+    return fail(HT_E_INVALID, "width and height must be >= 2 (the reference divides by W-1 and H-1)");
+  if ((int64_t)p->width * p->height > (int64_t)1 << 30) return fail(HT_E_INVALID, "image too large");
+  if (p->samples < 1) return fail(HT_E_INVALID, "samples must be >= 1");
+  if (p->sample_offset < 0) return fail(HT_E_INVALID, "sample_offset must be >= 0");
+  if ((int64_t)p->sample_offset + (int64_t)p->samples > (int64_t)INT32_MAX)
+    return fail(HT_E_INVALID, "sample_offset + samples exceeds 2^31 - 1");
+  if (p->precision != HT_PRECISION_FP32 && p->precision != HT_PRECISION_FP64)
+    return fail(HT_E_INVALID, "unknown precision %d", p->precision);
+  if (s && p->device >= 0 && p->device != s->device)
+    return fail(HT_E_INVALID, "scene lives on device %d, params ask for %d", s->device, p->device);
+  return HT_OK;
+}
+
+// Workgroup size and count of the render kernel for this scene: the combination that keeps
+// the most waves resident per CU; smaller groups win ties (measured on the Cornell box, 32
+// waves per CU either way: 256 x 8 34.2, 512 x 4 32.8, 1024 x 2 27.7 G samples/s).  Worked out
+// once per scene, precision and kernel variant (the occupancy queries cost host time on every
+// batch of a progressive frame otherwise) and again only after ht_set_option changed one of
+// the options it depends on.  The device must be current.
+int launch_shape(ht_scene* s, int prec, bool counters, LaunchShape& out) {
+  std::lock_guard<std::mutex> lock(s->shape_mutex);
+  LaunchShape& c = s->shape[prec][counters ? 1 : 0];
+  const int gen = g_shape_generation.load();
+  if (c.generation != gen) {
+    const SceneLayout& L = prec == HT_PRECISION_FP32 ? s->hs.layout32 : s->hs.layout64;
+    const uint32_t kfeat = s->feat | (L.tree_kinds == TREE_TRIANGLES ? KFEAT_TRIS : 0u);
+    LaunchShape best;
+    const int forced = g_block_threads.load();
+    for (int t = 256; t <= (int)max_block_threads(prec); t += 128) {
+      if (forced > 0 && t != forced) continue;
+      const uint32_t need = lds_bytes_needed(L, (uint32_t)t);
+      int b = render_blocks_per_cu(prec, counters, kfeat, L.wide != 0u, t, need);
+      b = std::min(b, g_max_blocks_per_cu.load());
+      // several workgroups share a CU well only when each fills the four SIMDs evenly: two
+      // groups of 14 waves (measured on the Cornell box) ran 20 % slower than two of 12
+      if (b > 1 && t % 256 != 0) b = 1;
+      if (b * t > best.bpc * best.threads) { best.threads = t; best.bpc = b; best.lds = need; }
+    }
+    best.generation = gen;
+    c = best;
+  }
+  if (c.bpc <= 0) {
+    const SceneLayout& L = prec == HT_PRECISION_FP32 ? s->hs.layout32 : s->hs.layout64;
+    return fail(HT_E_TOO_LARGE, "the render kernel cannot be resident with this scene (%u bytes of scene image)",
+                L.total_bytes);
+  }
+  out = c;
+  return HT_OK;
+}
+
+// Everything the launches of one call share.
+struct RenderPlan {
+  RenderArgs a;
+  CamDev<float> cam32;
+  CamDev<double> cam64;
+  const void* camp = nullptr;
+  LaunchShape shape;
+  uint32_t kfeat = 0;
+  int prec = 0;
+  bool counters = false;
+  int grid = 0;
+  int batch = 0;
+};
+
+int make_plan(ht_scene* s, const ht_camera* cam, const ht_render_params* p, int64_t* accum_dev, RenderPlan& pl) {
+  pl.prec = p->precision;
+  pl.counters = p->collect_counters != 0;
+  int rc = launch_shape(s, pl.prec, pl.counters, pl.shape);
+  if (rc != HT_OK) return rc;
+  const SceneLayout& L = pl.prec == HT_PRECISION_FP32 ? s->hs.layout32 : s->hs.layout64;
+  pl.kfeat = s->feat | (L.tree_kinds == TREE_TRIANGLES ? KFEAT_TRIS : 0u);
+  pl.grid = pl.shape.bpc * s->n_cu;
+
+  CameraBasis basis;
+  camera_basis(*cam, basis);
+  fill_cam(basis, pl.cam32);
+  fill_cam(basis, pl.cam64);
+  pl.camp = pl.prec == HT_PRECISION_FP32 ? (const void*)&pl.cam32 : (const void*)&pl.cam64;
+
+  RenderArgs& a = pl.a;
+  memset(&a, 0, sizeof a);
+  a.blob = pl.prec == HT_PRECISION_FP32 ? s->d_blob32 : s->d_blob64;
+  a.L = L;
+  a.texels = s->d_texels;
+  a.accum = (long long*)accum_dev;
+  a.chunk = std::max(1, g_chunk.load());
+  a.chunk_tail = std::min(a.chunk, std::max(1, g_chunk_tail.load()));
+  a.counters = pl.counters ? s->d_counters : nullptr;
+  a.W = p->width;
+  a.H = p->height;
+  a.max_depth = p->max_depth > 0 ? p->max_depth : 50;
+  a.jitter = p->jitter ? 1 : 0;
+  a.seed_lo = (uint32_t)p->seed;
+  a.seed_hi = (uint32_t)(p->seed >> 32);
+  for (uint32_t r = 0; r < 10; ++r) {
+    a.philox_keys[2 * r] = a.seed_lo + r * 0x9E3779B9u;
+    a.philox_keys[2 * r + 1] = a.seed_hi + r * 0xBB67AE85u;
+  }
+  a.wait_threshold = g_wait_threshold.load();
+  a.node_den = g_node_den.load();
+  a.wait_ratio_num = g_wait_num.load();
+  a.wait_ratio_den = g_wait_den.load();
+
+  int batch = p->batch > 0 ? p->batch : g_default_batch.load();
+  // the work queue of one launch is indexed with 32 bits: tiles x sample chunks
+  const int64_t tiles = (int64_t)((p->width + TILE_W - 1) / TILE_W) * ((p->height + TILE_H - 1) / TILE_H);
+  const int64_t max_chunks = std::max<int64_t>(1, ((int64_t)1 << 31) / tiles - 1 - a.chunk);
+  pl.batch = (int)std::min<int64_t>(batch, max_chunks * a.chunk);
+  return HT_OK;
+}
+
+// One launch of the plan: samples [first, first + count) of every pixel, its own queue head.
+hipError_t enqueue_launch(const RenderPlan& pl, uint32_t* queue_head, int first, int count, hipStream_t stream) {
+  RenderArgs a = pl.a;
+  a.sample_first = first;
+  a.sample_count = count;
+  a.tile_counter = queue_head;
+  hipError_t e = hipMemsetAsync(queue_head, 0, QUEUE_SLOT_BYTES, stream);
+  if (e == hipSuccess)
+    e = launch_render(pl.prec, pl.counters, pl.kfeat, a, pl.camp, pl.grid, pl.shape.threads, pl.shape.lds, stream);
+  return e;
+}
+
+uint32_t* next_queue_head(ht_scene* s) {
+  return (uint32_t*)(s->d_queue_heads + (size_t)(s->next_head.fetch_add(1) % QUEUE_SLOTS) * QUEUE_SLOT_BYTES);
+}
+
+// ht_render_accumulate without the argument checks that its callers share.
+// clear_cancel: a cancel request that arrived before this call belongs to an earlier frame
+// (the reference's shouldBreak only stops the frame in flight, main.scala:80) and is dropped.
+int render_accumulate_impl(ht_scene* s, const ht_camera* cam, const ht_render_params* p, int64_t* accum_dev,
+                           hipStream_t stream, ht_stats* stats, bool clear_cancel) {
+  if (clear_cancel) s->cancel.store(0);
+  const auto t0 = std::chrono::steady_clock::now();
+  DeviceGuard g(s->device);
+  if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
+
+  RenderPlan pl;
+  int rc = make_plan(s, cam, p, accum_dev, pl);
+  if (rc != HT_OK) return rc;
+  if (pl.counters) HIP_TRY(hipMemsetAsync(s->d_counters, 0, NUM_COUNTERS * sizeof(unsigned long long), stream));
+
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_batch[2] = {nullptr, nullptr};
+  auto cleanup = [&]() {
+    if (ev_start) (void)hipEventDestroy(ev_start);
+    if (ev_stop) (void)hipEventDestroy(ev_stop);
+    if (ev_batch[0]) (void)hipEventDestroy(ev_batch[0]);
+    if (ev_batch[1]) (void)hipEventDestroy(ev_batch[1]);
+  };
+  {
+    hipError_t ce = hipEventCreate(&ev_start);
+    if (ce == hipSuccess) ce = hipEventCreate(&ev_stop);
+    if (ce == hipSuccess) ce = hipEventCreateWithFlags(&ev_batch[0], hipEventDisableTiming);
+    if (ce == hipSuccess) ce = hipEventCreateWithFlags(&ev_batch[1], hipEventDisableTiming);
+    if (ce != hipSuccess) {
+      (void)hipGetLastError();
+      cleanup();
+      return fail(HT_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(ce));
+    }
+  }
+
+  int launches = 0, done = 0;
+  bool cancelled = false;
+  hipError_t e = hipEventRecord(ev_start, stream);
+  while (e == hipSuccess && done < p->samples) {
+    // keep at most two batches in flight so that a cancel request is seen soon
+    if (launches >= 2) e = hipEventSynchronize(ev_batch[launches & 1]);
+    if (e != hipSuccess) break;
+    if (s->cancel.exchange(0)) { cancelled = true; break; }
+    const int count = std::min(pl.batch, p->samples - done);
+    e = enqueue_launch(pl, next_queue_head(s), p->sample_offset + done, count, stream);
+    if (e == hipSuccess) e = hipEventRecord(ev_batch[launches & 1], stream);
+    if (e == hipSuccess) {
+      done += count;
+      launches++;
+    }
+  }
+  if (e == hipSuccess) e = hipEventRecord(ev_stop, stream);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    cleanup();
+    return fail(HT_E_HIP, "render launch failed: %s", hipGetErrorString(e));
+  }
+  if (stats) {
+    memset(stats, 0, sizeof *stats);
+    e = hipEventSynchronize(ev_stop);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev_start, ev_stop);
+    if (e == hipSuccess && pl.counters) {
+      unsigned long long h[NUM_COUNTERS];
+      e = hipMemcpy(h, s->d_counters, sizeof h, hipMemcpyDeviceToHost);
+      if (e == hipSuccess) {
+        stats->n_rays = (int64_t)h[CTR_RAYS];
+        stats->n_box = (int64_t)h[CTR_BOX];
+        stats->n_sphere = (int64_t)h[CTR_SPHERE];
+        stats->n_rect = (int64_t)h[CTR_RECT];
+        stats->n_tri = (int64_t)h[CTR_TRI];
+        for (int k = 0; k < 4; ++k) {
+          stats->n_shade[k] = (int64_t)h[CTR_SHADE0 + k];
+          stats->n_tex[k] = (int64_t)h[CTR_TEX0 + k];
+        }
+        stats->n_steps = (int64_t)h[CTR_STEPS];
+        stats->n_active = (int64_t)h[CTR_ACTIVE];
+        stats->n_shade_rounds = (int64_t)h[CTR_SHADE_ROUNDS];
+        stats->n_regen_rounds = (int64_t)h[CTR_REGEN_ROUNDS];
+        stats->n_miss = (int64_t)h[CTR_MISS];
+        stats->cyc_trav = (int64_t)h[CTR_CYC_TRAV];
+        stats->cyc_shade = (int64_t)h[CTR_CYC_SHADE];
+        stats->cyc_regen = (int64_t)h[CTR_CYC_REGEN];
+        if (h[CTR_CLK_REAL]) stats->shader_clock_mhz = 100.0 * (double)h[CTR_CLK_SHADER] / (double)h[CTR_CLK_REAL];
+      }
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      cleanup();
+      return fail(HT_E_HIP, "render failed on the device: %s", hipGetErrorString(e));
+    }
+    stats->block_threads = pl.shape.threads;
+    stats->blocks_per_cu = pl.shape.bpc;
+    stats->lds_bytes = (int32_t)pl.shape.lds;
+    stats->n_cu = s->n_cu;
+    stats->seconds_kernel = ms * 1e-3;
+    stats->launches = launches;
+    stats->samples = (int64_t)p->width * p->height * done;  // what was launched, also when cancelled
+    stats->seconds_total =
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  cleanup();
+  if (cancelled) return fail(HT_E_CANCELLED, "render cancelled after %d batches (%d samples per pixel)", launches, done);
+  return HT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -130,16 +395,16 @@ int ht_device_count(void) {
   return n;
 }
 
-const char* ht_last_error(void) { return g_error.c_str(); }
+const char* ht_last_error(void) { return g_error; }
 
 int ht_set_option(const char* name, int value) {
   if (!name) return fail(HT_E_INVALID, "option name is NULL");
   if (!strcmp(name, "wait_threshold")) { g_wait_threshold = std::min(64, std::max(1, value)); return HT_OK; }
-  if (!strcmp(name, "max_blocks_per_cu")) { g_max_blocks_per_cu = std::max(1, value); return HT_OK; }
+  if (!strcmp(name, "max_blocks_per_cu")) { g_max_blocks_per_cu = std::max(1, value); g_shape_generation++; return HT_OK; }
   if (!strcmp(name, "default_batch")) { g_default_batch = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "chunk")) { g_chunk = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "chunk_tail")) { g_chunk_tail = std::max(1, value); return HT_OK; }
-  if (!strcmp(name, "block_threads")) { g_block_threads = value; return HT_OK; }
+  if (!strcmp(name, "block_threads")) { g_block_threads = value; g_shape_generation++; return HT_OK; }
   if (!strcmp(name, "node_den")) { g_node_den = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "wait_ratio_num")) { g_wait_num = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "wait_ratio_den")) { g_wait_den = std::max(1, value); return HT_OK; }
@@ -154,7 +419,7 @@ void ht_scene_destroy(ht_scene* s) {
     if (s->d_blob32) (void)hipFree(s->d_blob32);
     if (s->d_blob64) (void)hipFree(s->d_blob64);
     if (s->d_texels) (void)hipFree(s->d_texels);
-    if (s->d_tile_counter) (void)hipFree(s->d_tile_counter);
+    if (s->d_queue_heads) (void)hipFree(s->d_queue_heads);
     if (s->d_counters) (void)hipFree(s->d_counters);
   }
   delete s;
@@ -163,6 +428,7 @@ void ht_scene_destroy(ht_scene* s) {
 int ht_scene_create(const ht_scene_desc* desc, int device, ht_scene** out) {
   if (!out) return fail(HT_E_INVALID, "out is NULL");
   *out = nullptr;
+  HT_API_TRY
   const int ndev = ht_device_count();
   if (ndev <= 0) return fail(HT_E_NO_DEVICE, "no HIP device is visible; libhiptrace has no CPU path");
   if (device < 0) {
@@ -214,15 +480,22 @@ int ht_scene_create(const ht_scene_desc* desc, int device, ht_scene** out) {
   if (e == hipSuccess) e = upload(s->hs.blob64.data(), s->hs.blob64.size(), (void**)&s->d_blob64);
   if (e == hipSuccess)
     e = upload(s->hs.image_texels.data(), s->hs.image_texels.size() * 4, (void**)&s->d_texels);
-  if (e == hipSuccess) e = hipMalloc((void**)&s->d_tile_counter, 256);
+  if (e == hipSuccess) e = hipMalloc((void**)&s->d_queue_heads, (size_t)QUEUE_SLOTS * QUEUE_SLOT_BYTES);
   if (e == hipSuccess) e = hipMalloc((void**)&s->d_counters, NUM_COUNTERS * sizeof(unsigned long long));
   if (e != hipSuccess) {
     (void)hipGetLastError();
     ht_scene_destroy(s);
     return fail(HT_E_HIP, "device allocation / upload failed: %s", hipGetErrorString(e));
   }
+  // the launch shapes of the two production variants, so that no render call pays for them
+  {
+    LaunchShape sh;
+    (void)launch_shape(s, HT_PRECISION_FP32, false, sh);  // a scene too large for a variant fails when rendered
+    (void)launch_shape(s, HT_PRECISION_FP64, false, sh);
+  }
   *out = s;
   return HT_OK;
+  HT_API_CATCH
 }
 
 int ht_scene_get_info(const ht_scene* s, ht_scene_info* out) {
@@ -251,174 +524,11 @@ int ht_render_accumulate(ht_scene* s, const ht_camera* cam, const ht_render_para
   if (!s || !p || !accum_dev) return fail(HT_E_INVALID, "NULL argument");
   int rc = check_camera(cam);
   if (rc != HT_OK) return rc;
-  if (p->width < 2 || p->height < 2)
-    return fail(HT_E_INVALID, "width and height must be >= 2 (the reference divides by W-1 and H-1)");
-  if ((int64_t)p->width * p->height > (int64_t)1 << 30) return fail(HT_E_INVALID, "image too large");
-  if (p->samples < 1) return fail(HT_E_INVALID, "samples must be >= 1");
-  if (p->sample_offset < 0) return fail(HT_E_INVALID, "sample_offset must be >= 0");
-  if (p->precision != HT_PRECISION_FP32 && p->precision != HT_PRECISION_FP64)
-    return fail(HT_E_INVALID, "unknown precision %d", p->precision);
-  if (p->device >= 0 && p->device != s->device)
-    return fail(HT_E_INVALID, "scene lives on device %d, params ask for %d", s->device, p->device);
-  const auto t0 = std::chrono::steady_clock::now();
-  hipStream_t stream = (hipStream_t)stream_v;
-  DeviceGuard g(s->device);
-  if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
-
-  const int prec = p->precision;
-  const bool counters = p->collect_counters != 0;
-  const SceneLayout& L = prec == HT_PRECISION_FP32 ? s->hs.layout32 : s->hs.layout64;
-  const uint32_t kfeat = s->feat | (L.tree_kinds == TREE_TRIANGLES ? KFEAT_TRIS : 0u);
-  // workgroup size and count: the combination that keeps the most waves resident per CU;
-  // smaller groups win ties (measured on the Cornell box, 32 waves per CU either way:
-  // 256 x 8 34.2, 512 x 4 32.8, 1024 x 2 27.7 G samples/s)
-  int threads = 0, bpc = 0;
-  uint32_t lds = 0;
-  const int forced = g_block_threads.load();
-  for (int t = 256; t <= (int)max_block_threads(prec); t += 128) {
-    if (forced > 0 && t != forced) continue;
-    const uint32_t need = lds_bytes_needed(L, (uint32_t)t);
-    int b = render_blocks_per_cu(prec, counters, kfeat, L.wide != 0u, t, need);
-    b = std::min(b, g_max_blocks_per_cu.load());
-    // several workgroups share a CU well only when each fills the four SIMDs evenly: two
-    // groups of 14 waves (measured on the Cornell box) ran 20 % slower than two of 12
-    if (b > 1 && t % 256 != 0) b = 1;
-    if (b * t > bpc * threads) { threads = t; bpc = b; lds = need; }
-  }
-  if (bpc <= 0)
-    return fail(HT_E_TOO_LARGE, "the render kernel cannot be resident with this scene (%u bytes of scene image)",
-                L.total_bytes);
-  const int grid = bpc * s->n_cu;
-
-  CameraBasis basis;
-  camera_basis(*cam, basis);
-  CamDev<float> cam32;
-  CamDev<double> cam64;
-  fill_cam(basis, cam32);
-  fill_cam(basis, cam64);
-  const void* camp = prec == HT_PRECISION_FP32 ? (const void*)&cam32 : (const void*)&cam64;
-
-  RenderArgs a;
-  memset(&a, 0, sizeof a);
-  a.blob = prec == HT_PRECISION_FP32 ? s->d_blob32 : s->d_blob64;
-  a.L = L;
-  a.texels = s->d_texels;
-  a.accum = (long long*)accum_dev;
-  a.chunk = std::max(1, g_chunk.load());
-  a.chunk_tail = std::min(a.chunk, std::max(1, g_chunk_tail.load()));
-  a.tile_counter = s->d_tile_counter;
-  a.counters = counters ? s->d_counters : nullptr;
-  a.W = p->width;
-  a.H = p->height;
-  a.max_depth = p->max_depth > 0 ? p->max_depth : 50;
-  a.jitter = p->jitter ? 1 : 0;
-  a.seed_lo = (uint32_t)p->seed;
-  a.seed_hi = (uint32_t)(p->seed >> 32);
-  for (uint32_t r = 0; r < 10; ++r) {
-    a.philox_keys[2 * r] = a.seed_lo + r * 0x9E3779B9u;
-    a.philox_keys[2 * r + 1] = a.seed_hi + r * 0xBB67AE85u;
-  }
-  a.wait_threshold = g_wait_threshold.load();
-  a.node_den = g_node_den.load();
-  a.wait_ratio_num = g_wait_num.load();
-  a.wait_ratio_den = g_wait_den.load();
-
-  if (counters) HIP_TRY(hipMemsetAsync(s->d_counters, 0, NUM_COUNTERS * sizeof(unsigned long long), stream));
-
-  hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_batch[2] = {nullptr, nullptr};
-  auto cleanup = [&]() {
-    if (ev_start) (void)hipEventDestroy(ev_start);
-    if (ev_stop) (void)hipEventDestroy(ev_stop);
-    if (ev_batch[0]) (void)hipEventDestroy(ev_batch[0]);
-    if (ev_batch[1]) (void)hipEventDestroy(ev_batch[1]);
-  };
-  {
-    hipError_t ce = hipEventCreate(&ev_start);
-    if (ce == hipSuccess) ce = hipEventCreate(&ev_stop);
-    if (ce == hipSuccess) ce = hipEventCreateWithFlags(&ev_batch[0], hipEventDisableTiming);
-    if (ce == hipSuccess) ce = hipEventCreateWithFlags(&ev_batch[1], hipEventDisableTiming);
-    if (ce != hipSuccess) {
-      (void)hipGetLastError();
-      cleanup();
-      return fail(HT_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(ce));
-    }
-  }
-
-  int batch = p->batch > 0 ? p->batch : g_default_batch.load();
-  {
-    // the work queue of one launch is indexed with 32 bits: tiles x sample chunks
-    const int64_t tiles = (int64_t)((p->width + TILE_W - 1) / TILE_W) * ((p->height + TILE_H - 1) / TILE_H);
-    const int64_t max_chunks = std::max<int64_t>(1, ((int64_t)1 << 31) / tiles - 1 - a.chunk);
-    batch = (int)std::min<int64_t>(batch, max_chunks * a.chunk);
-  }
-  int launches = 0;
-  bool cancelled = false;
-  hipError_t e = hipEventRecord(ev_start, stream);
-  for (int done = 0; e == hipSuccess && done < p->samples; done += batch) {
-    // keep at most two batches in flight so that a cancel request is seen soon
-    if (launches >= 2) e = hipEventSynchronize(ev_batch[launches & 1]);
-    if (e != hipSuccess) break;
-    if (s->cancel.exchange(0)) { cancelled = true; break; }
-    a.sample_first = p->sample_offset + done;
-    a.sample_count = std::min(batch, p->samples - done);
-    e = hipMemsetAsync(s->d_tile_counter, 0, 256, stream);
-    if (e == hipSuccess) e = launch_render(prec, counters, kfeat, a, camp, grid, threads, lds, stream);
-    if (e == hipSuccess) e = hipEventRecord(ev_batch[launches & 1], stream);
-    launches++;
-  }
-  if (e == hipSuccess) e = hipEventRecord(ev_stop, stream);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    cleanup();
-    return fail(HT_E_HIP, "render launch failed: %s", hipGetErrorString(e));
-  }
-  if (stats) {
-    memset(stats, 0, sizeof *stats);
-    e = hipEventSynchronize(ev_stop);
-    float ms = 0;
-    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev_start, ev_stop);
-    if (e == hipSuccess && counters) {
-      unsigned long long h[NUM_COUNTERS];
-      e = hipMemcpy(h, s->d_counters, sizeof h, hipMemcpyDeviceToHost);
-      if (e == hipSuccess) {
-        stats->n_rays = (int64_t)h[CTR_RAYS];
-        stats->n_box = (int64_t)h[CTR_BOX];
-        stats->n_sphere = (int64_t)h[CTR_SPHERE];
-        stats->n_rect = (int64_t)h[CTR_RECT];
-        stats->n_tri = (int64_t)h[CTR_TRI];
-        for (int k = 0; k < 4; ++k) {
-          stats->n_shade[k] = (int64_t)h[CTR_SHADE0 + k];
-          stats->n_tex[k] = (int64_t)h[CTR_TEX0 + k];
-        }
-        stats->n_steps = (int64_t)h[CTR_STEPS];
-        stats->n_active = (int64_t)h[CTR_ACTIVE];
-        stats->n_shade_rounds = (int64_t)h[CTR_SHADE_ROUNDS];
-        stats->n_regen_rounds = (int64_t)h[CTR_REGEN_ROUNDS];
-        stats->n_miss = (int64_t)h[CTR_MISS];
-        stats->cyc_trav = (int64_t)h[CTR_CYC_TRAV];
-        stats->cyc_shade = (int64_t)h[CTR_CYC_SHADE];
-        stats->cyc_regen = (int64_t)h[CTR_CYC_REGEN];
-        if (h[CTR_CLK_REAL]) stats->shader_clock_mhz = 100.0 * (double)h[CTR_CLK_SHADER] / (double)h[CTR_CLK_REAL];
-      }
-    }
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      cleanup();
-      return fail(HT_E_HIP, "render failed on the device: %s", hipGetErrorString(e));
-    }
-    stats->block_threads = threads;
-    stats->blocks_per_cu = bpc;
-    stats->lds_bytes = (int32_t)lds;
-    stats->n_cu = s->n_cu;
-    stats->seconds_kernel = ms * 1e-3;
-    stats->launches = launches;
-    stats->samples = (int64_t)p->width * p->height * (cancelled ? (int64_t)(launches)*batch : p->samples);
-    stats->seconds_total =
-        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  }
-  cleanup();
-  if (cancelled) return fail(HT_E_CANCELLED, "render cancelled after %d batches", launches);
-  return HT_OK;
+  rc = check_params(s, p);
+  if (rc != HT_OK) return rc;
+  HT_API_TRY
+  return render_accumulate_impl(s, cam, p, accum_dev, (hipStream_t)stream_v, stats, true);
+  HT_API_CATCH
 }
 
 int ht_resolve_device(ht_scene* s, const int64_t* accum_dev, int32_t W, int32_t H, int64_t total_samples,
@@ -468,8 +578,11 @@ int ht_resolve(ht_scene* s, const int64_t* accum_dev, int32_t W, int32_t H, int6
 int ht_render(ht_scene* s, const ht_camera* cam, const ht_render_params* p, float* rgb_linear,
               uint32_t* rgb_packed, ht_stats* stats_out) {
   if (!s || !p) return fail(HT_E_INVALID, "NULL argument");
-  if (p->width < 2 || p->height < 2)
-    return fail(HT_E_INVALID, "width and height must be >= 2 (the reference divides by W-1 and H-1)");
+  int rc = check_camera(cam);
+  if (rc != HT_OK) return rc;
+  rc = check_params(s, p);
+  if (rc != HT_OK) return rc;
+  HT_API_TRY
   const auto t0 = std::chrono::steady_clock::now();
   DeviceGuard g(s->device);
   if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
@@ -482,7 +595,7 @@ int ht_render(ht_scene* s, const ht_camera* cam, const ht_render_params* p, floa
     return fail(HT_E_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
   }
   ht_stats st;
-  int rc = ht_render_accumulate(s, cam, p, d_accum, nullptr, &st);
+  rc = render_accumulate_impl(s, cam, p, d_accum, nullptr, &st, true);
   if (rc == HT_OK)
     rc = ht_resolve(s, d_accum, p->width, p->height, p->samples, rgb_linear, rgb_packed, nullptr);
   (void)hipFree(d_accum);
@@ -492,6 +605,7 @@ int ht_render(ht_scene* s, const ht_camera* cam, const ht_render_params* p, floa
         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
   return rc;
+  HT_API_CATCH
 }
 
 int ht_render_sharded(ht_scene* const* scenes, int32_t n, const ht_camera* cam, const ht_render_params* p,
@@ -508,16 +622,17 @@ int ht_render_sharded(ht_scene* const* scenes, int32_t n, const ht_camera* cam, 
   }
   int rc = check_camera(cam);
   if (rc != HT_OK) return rc;
-  if (p->width < 2 || p->height < 2)
-    return fail(HT_E_INVALID, "width and height must be >= 2 (the reference divides by W-1 and H-1)");
-  if ((int64_t)p->width * p->height > (int64_t)1 << 30) return fail(HT_E_INVALID, "image too large");
-  if (p->samples < 1) return fail(HT_E_INVALID, "samples must be >= 1");
+  rc = check_params(nullptr, p);
+  if (rc != HT_OK) return rc;
+  HT_API_TRY
   const auto t0 = std::chrono::steady_clock::now();
   const size_t words = (size_t)p->width * p->height * 3;
   const size_t bytes = words * sizeof(int64_t);
+  for (int k = 0; k < n; ++k) scenes[k]->cancel.store(0);  // requests older than this frame
 
   struct Shard {
     int64_t* d_accum = nullptr;
+    int64_t* d_staging = nullptr;  // the other shards' copies of this shard's slice
     ht_render_params params;
     ht_stats stats;
     int rc = HT_OK;
@@ -525,12 +640,20 @@ int ht_render_sharded(ht_scene* const* scenes, int32_t n, const ht_camera* cam, 
   };
   std::vector<Shard> shards((size_t)n);
   auto release = [&]() {
-    for (int k = 0; k < n; ++k)
-      if (shards[(size_t)k].d_accum) {
-        DeviceGuard g(scenes[k]->device);
-        (void)hipFree(shards[(size_t)k].d_accum);
-      }
+    for (int k = 0; k < n; ++k) {
+      DeviceGuard g(scenes[k]->device);
+      if (shards[(size_t)k].d_accum) (void)hipFree(shards[(size_t)k].d_accum);
+      if (shards[(size_t)k].d_staging) (void)hipFree(shards[(size_t)k].d_staging);
+    }
   };
+  // Slice k of the frame is summed on shard k's device (words [lo_k, hi_k), 16-byte aligned):
+  // every device pulls its slice from every other one at the same time, each pair over its
+  // own xGMI link, and adds what arrived; then the summed slices go to the first device.
+  // That is a reduce-scatter and a gather written out as peer copies: the combine costs two
+  // messages of 1/n of the frame per link instead of n - 1 whole frames through one device.
+  std::vector<size_t> lo((size_t)n + 1);
+  for (int k = 0; k <= n; ++k) lo[(size_t)k] = std::min(words, ((words * (size_t)k / (size_t)n) + 1) & ~(size_t)1);
+  lo[(size_t)n] = words;
   for (int k = 0; k < n; ++k) {
     Shard& sh = shards[(size_t)k];
     const int64_t first = (int64_t)k * p->samples / n, last = (int64_t)(k + 1) * p->samples / n;
@@ -540,8 +663,11 @@ int ht_render_sharded(ht_scene* const* scenes, int32_t n, const ht_camera* cam, 
     sh.params.device = -1;
     memset(&sh.stats, 0, sizeof sh.stats);
     DeviceGuard g(scenes[k]->device);
+    const size_t slice = lo[(size_t)k + 1] - lo[(size_t)k];
     hipError_t e = g.ok ? hipMalloc((void**)&sh.d_accum, bytes) : hipErrorInvalidDevice;
     if (e == hipSuccess) e = hipMemset(sh.d_accum, 0, bytes);
+    if (e == hipSuccess && n > 1 && slice > 0)
+      e = hipMalloc((void**)&sh.d_staging, slice * (size_t)(n - 1) * sizeof(int64_t));
     if (e != hipSuccess) {
       (void)hipGetLastError();
       release();
@@ -556,8 +682,12 @@ int ht_render_sharded(ht_scene* const* scenes, int32_t n, const ht_camera* cam, 
       ht_scene* sc = scenes[k];
       if (sh->params.samples < 1) continue;  // more shards than samples
       workers.emplace_back([sh, sc, cam]() {
-        sh->rc = ht_render_accumulate(sc, cam, &sh->params, sh->d_accum, nullptr, &sh->stats);
-        if (sh->rc != HT_OK) sh->error = ht_last_error();  // the message is per thread: carry it over
+        try {
+          sh->rc = render_accumulate_impl(sc, cam, &sh->params, sh->d_accum, nullptr, &sh->stats, false);
+          if (sh->rc != HT_OK) sh->error = ht_last_error();  // the message is per thread: carry it over
+        } catch (...) {
+          sh->rc = HT_E_INVALID;
+        }
       });
     }
     for (auto& w : workers) w.join();
@@ -569,31 +699,56 @@ int ht_render_sharded(ht_scene* const* scenes, int32_t n, const ht_camera* cam, 
       release();
       return fail(code, "shard %d: %s", k, msg.c_str());
     }
-  // bring the partial sums to device 0 of the list and add them there
-  {
-    const int dev0 = scenes[0]->device;
-    DeviceGuard g(dev0);
-    if (!g.ok) { release(); return fail(HT_E_NO_DEVICE, "cannot select device %d", dev0); }
-    int64_t* staging = nullptr;
+  if (n > 1) {
     hipError_t e = hipSuccess;
-    for (int k = 1; k < n && e == hipSuccess; ++k) {
-      if (shards[(size_t)k].params.samples < 1) continue;
-      const int devk = scenes[k]->device;
-      const long long* src = (const long long*)shards[(size_t)k].d_accum;
-      if (devk != dev0) {
-        // direct device-to-device copies where the link allows them (already enabled, or
-        // not possible: the copy then goes through the host, which is still correct)
+    // peer access where the links allow it (already enabled, or not possible: the copies then
+    // go through the host, which is still correct)
+    for (int k = 0; k < n; ++k)
+      for (int j = 0; j < n; ++j) {
+        const int dk = scenes[k]->device, dj = scenes[j]->device;
+        if (dk == dj) continue;
+        DeviceGuard g(dk);
         int can = 0;
-        if (hipDeviceCanAccessPeer(&can, dev0, devk) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(devk, 0);
+        if (hipDeviceCanAccessPeer(&can, dk, dj) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(dj, 0);
         (void)hipGetLastError();
-        if (!staging) e = hipMalloc((void**)&staging, bytes);
-        if (e == hipSuccess) e = hipMemcpyPeer(staging, dev0, shards[(size_t)k].d_accum, devk, bytes);
-        src = (const long long*)staging;
       }
-      if (e == hipSuccess) e = launch_accum_add((long long*)shards[0].d_accum, src, words, nullptr);
-      if (e == hipSuccess) e = hipStreamSynchronize(nullptr);  // staging is reused by the next shard
+    // reduce-scatter: all devices at once, nothing waits on the host in between
+    for (int k = 0; k < n && e == hipSuccess; ++k) {
+      Shard& sh = shards[(size_t)k];
+      const size_t slice = lo[(size_t)k + 1] - lo[(size_t)k];
+      if (slice == 0) continue;
+      const int dk = scenes[k]->device;
+      DeviceGuard g(dk);
+      int slot = 0;
+      for (int j = 0; j < n && e == hipSuccess; ++j) {
+        if (j == k || shards[(size_t)j].params.samples < 1) continue;
+        e = hipMemcpyPeerAsync(sh.d_staging + (size_t)slot * slice, dk, shards[(size_t)j].d_accum + lo[(size_t)k],
+                               scenes[j]->device, slice * sizeof(int64_t), nullptr);
+        slot++;
+      }
+      if (e == hipSuccess && slot > 0)
+        e = launch_accum_add_many((long long*)sh.d_accum + lo[(size_t)k], (const long long*)sh.d_staging, slice, slot,
+                                  nullptr);
     }
-    if (staging) (void)hipFree(staging);
+    for (int k = 0; k < n; ++k) {
+      DeviceGuard g(scenes[k]->device);
+      const hipError_t se = hipStreamSynchronize(nullptr);
+      if (e == hipSuccess) e = se;
+    }
+    // gather: every device sends its summed slice to the first one, all at once
+    for (int k = 1; k < n && e == hipSuccess; ++k) {
+      const size_t slice = lo[(size_t)k + 1] - lo[(size_t)k];
+      if (slice == 0) continue;
+      DeviceGuard g(scenes[k]->device);
+      e = hipMemcpyPeerAsync(shards[0].d_accum + lo[(size_t)k], scenes[0]->device,
+                             shards[(size_t)k].d_accum + lo[(size_t)k], scenes[k]->device,
+                             slice * sizeof(int64_t), nullptr);
+    }
+    for (int k = 1; k < n; ++k) {
+      DeviceGuard g(scenes[k]->device);
+      const hipError_t se = hipStreamSynchronize(nullptr);
+      if (e == hipSuccess) e = se;
+    }
     if (e != hipSuccess) {
       (void)hipGetLastError();
       release();
@@ -613,6 +768,7 @@ int ht_render_sharded(ht_scene* const* scenes, int32_t n, const ht_camera* cam, 
     stats_out->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
   return rc;
+  HT_API_CATCH
 }
 
 int ht_frame_create(ht_scene* s, int32_t W, int32_t H, ht_frame** out) {
@@ -663,14 +819,20 @@ int ht_frame_accumulate(ht_frame* f, const ht_camera* cam, const ht_render_param
   if (!f || !p) return fail(HT_E_INVALID, "NULL argument");
   if (p->width != f->width || p->height != f->height)
     return fail(HT_E_INVALID, "params are %dx%d, the frame is %dx%d", p->width, p->height, f->width, f->height);
+  int rc = check_camera(cam);
+  if (rc != HT_OK) return rc;
+  rc = check_params(f->scene, p);
+  if (rc != HT_OK) return rc;
+  HT_API_TRY
   ht_stats st;
-  int rc = ht_render_accumulate(f->scene, cam, p, f->d_accum, nullptr, &st);
+  rc = render_accumulate_impl(f->scene, cam, p, f->d_accum, nullptr, &st, true);
   if (rc == HT_OK || rc == HT_E_CANCELLED) {
     // a cancelled call still added the batches it had launched
     f->samples += st.samples / ((int64_t)f->width * f->height);
     if (stats_out) *stats_out = st;
   }
   return rc;
+  HT_API_CATCH
 }
 
 int ht_frame_read(ht_frame* f, float* rgb_linear, uint32_t* rgb_packed) {
@@ -687,12 +849,15 @@ int ht_first_hit(ht_scene* s, const ht_camera* cam, int32_t W, int32_t H, int32_
   int rc = check_camera(cam);
   if (rc != HT_OK) return rc;
   if (W < 2 || H < 2) return fail(HT_E_INVALID, "width and height must be >= 2");
+  if ((int64_t)W * H > (int64_t)1 << 30) return fail(HT_E_INVALID, "image too large");
   if (precision != HT_PRECISION_FP32 && precision != HT_PRECISION_FP64)
     return fail(HT_E_INVALID, "unknown precision %d", precision);
+  HT_API_TRY
   DeviceGuard g(s->device);
   if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
   const size_t n = (size_t)W * H;
   const size_t rs = precision == HT_PRECISION_FP32 ? 4 : 8;
+  std::vector<uint8_t> ht_(n * rs), hn(n * 3 * rs);  // host staging, before anything is held on the device
   void *d_t = nullptr, *d_n = nullptr;
   int32_t* d_p = nullptr;
   hipError_t e = hipMalloc(&d_t, n * rs);
@@ -725,7 +890,6 @@ int ht_first_hit(ht_scene* s, const ht_camera* cam, int32_t W, int32_t H, int32_
   const uint32_t lds = lds_bytes_needed(a.L, fh_threads);
   e = launch_first_hit(precision, a, precision == HT_PRECISION_FP32 ? (const void*)&cam32 : (const void*)&cam64,
                        (int)fh_threads, lds, nullptr);
-  std::vector<uint8_t> ht_(n * rs), hn(n * 3 * rs);
   if (e == hipSuccess) e = hipMemcpy(ht_.data(), d_t, n * rs, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(hn.data(), d_n, n * 3 * rs, hipMemcpyDeviceToHost);
   if (e == hipSuccess && prim_id) e = hipMemcpy(prim_id, d_p, n * 4, hipMemcpyDeviceToHost);
@@ -758,6 +922,7 @@ int ht_first_hit(ht_scene* s, const ht_camera* cam, int32_t W, int32_t H, int32_
     }
   }
   return HT_OK;
+  HT_API_CATCH
 }
 
 }  // extern "C"

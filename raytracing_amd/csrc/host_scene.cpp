@@ -412,11 +412,35 @@ void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out, 
   out.resize(L.total_bytes);
 }
 
-bool texture_acyclic(const HostScene& hs, int t, int depth) {
-  if (depth > (int)hs.tex_type.size()) return false;
-  if (hs.tex_type[t] != HT_TEX_CHECKER) return true;
-  return texture_acyclic(hs, hs.tex_child[t * 2], depth + 1) &&
-         texture_acyclic(hs, hs.tex_child[t * 2 + 1], depth + 1);
+// Checker textures may share children (a DAG) but must not reach themselves.  Three-colour
+// depth-first search with an explicit stack: every texture is expanded once, so a chain of
+// checkers that name one child twice costs n steps, not 2^n.
+bool textures_acyclic(const HostScene& hs) {
+  const int n = (int)hs.tex_type.size();
+  std::vector<uint8_t> colour((size_t)n, 0);  // 0 unseen, 1 on the path, 2 finished
+  std::vector<std::pair<int, int>> path;      // (texture, next child to visit)
+  for (int root = 0; root < n; ++root) {
+    if (colour[(size_t)root]) continue;
+    path.push_back({root, 0});
+    colour[(size_t)root] = 1;
+    while (!path.empty()) {
+      const int t = path.back().first;
+      const int c = path.back().second;
+      if (hs.tex_type[(size_t)t] != HT_TEX_CHECKER || c == 2) {
+        colour[(size_t)t] = 2;
+        path.pop_back();
+        continue;
+      }
+      path.back().second++;
+      const int ch = hs.tex_child[(size_t)t * 2 + (size_t)c];
+      if (colour[(size_t)ch] == 1) return false;  // back edge
+      if (colour[(size_t)ch] == 0) {
+        colour[(size_t)ch] = 1;
+        path.push_back({ch, 0});
+      }
+    }
+  }
+  return true;
 }
 
 }  // namespace
@@ -442,6 +466,9 @@ int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err, co
   if ((uint32_t)d->n_materials > MAX_MATERIALS) { err = "too many materials"; return HT_E_TOO_LARGE; }
   if ((uint32_t)d->n_textures > MAX_TEXTURES) { err = "too many textures"; return HT_E_TOO_LARGE; }
   if (d->n_images < 0 || d->n_perlin < 0) { err = "negative table count"; return HT_E_INVALID; }
+  // a texture record names its Perlin table or image in 15 bits
+  if ((uint32_t)d->n_images > MAX_TEXTURES) { err = "too many images"; return HT_E_TOO_LARGE; }
+  if ((uint32_t)d->n_perlin > MAX_TEXTURES) { err = "too many perlin tables"; return HT_E_TOO_LARGE; }
 
   hs.prim_type.assign(d->prim_type, d->prim_type + d->n_prims);
   hs.prim_material.assign(d->prim_material, d->prim_material + d->n_prims);
@@ -493,8 +520,7 @@ int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err, co
       if (t < 0 || t >= d->n_images) { err = "image index out of range"; return HT_E_INVALID; }
     }
   }
-  for (int i = 0; i < d->n_textures; ++i)
-    if (!texture_acyclic(hs, i, 0)) { err = "checker textures form a cycle"; return HT_E_INVALID; }
+  if (!textures_acyclic(hs)) { err = "checker textures form a cycle"; return HT_E_INVALID; }
   for (int i = 0; i < d->n_materials; ++i) {
     if (hs.mat_type[i] < HT_MAT_DIFFUSE || hs.mat_type[i] > HT_MAT_EMISSION) {
       err = "unknown material type"; return HT_E_INVALID;

@@ -78,6 +78,8 @@ hipError_t launch_first_hit(int precision, const FirstHitArgs& a, const void* ca
                             uint32_t lds_bytes, hipStream_t stream);
 // dst[i] += src[i] over n radiance sums (combining the partial frames of sample shards)
 hipError_t launch_accum_add(long long* dst, const long long* src, size_t n, hipStream_t stream);
+// dst[i] += sum over j < count of src[j * n + i]: the other shards' copies of one slice of the frame
+hipError_t launch_accum_add_many(long long* dst, const long long* src, size_t n, int count, hipStream_t stream);
 // mean + Vec3.toRGB + row flip (Vec3.scala:82-84, main.scala:93)
 hipError_t launch_resolve(const long long* accum, int32_t W, int32_t H, double inv_samples,
                           float* rgb_mean, uint32_t* rgb_packed, hipStream_t stream);

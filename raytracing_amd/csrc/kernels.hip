@@ -1291,6 +1291,16 @@ __global__ void accum_add_kernel(long long* __restrict__ dst, const long long* _
   if (i < n) dst[i] += src[i];
 }
 
+// dst[i] += src[0][i] + src[1][i] + ... : one slice of the frame, `count` copies n words apart
+__global__ void accum_add_many_kernel(long long* __restrict__ dst, const long long* __restrict__ src, size_t n,
+                                      int count) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  long long v = dst[i];
+  for (int j = 0; j < count; ++j) v += src[(size_t)j * n + i];
+  dst[i] = v;
+}
+
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
@@ -1328,10 +1338,16 @@ const void* render_kernel_ptr(int precision, bool counters, uint32_t feat, bool 
 }
 }  // namespace
 
+// LDS a workgroup may ask for on gfx950; the kernels' dynamic-LDS limit is raised to it and
+// never lowered, so threads that work out launch shapes for different scenes cannot undo
+// each other's setting between the query and the launch.
+constexpr uint32_t LDS_LIMIT_BYTES = 160u * 1024u;
+
 int render_blocks_per_cu(int precision, bool counters, uint32_t feat, bool wide, int threads,
                          uint32_t lds_bytes) {
   const void* k = render_kernel_ptr(precision, counters, feat, wide);
-  if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) {
+  if (lds_bytes > LDS_LIMIT_BYTES) return 0;
+  if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT_BYTES) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
@@ -1359,7 +1375,8 @@ hipError_t launch_render(int precision, bool counters, uint32_t feat, const Rend
 template <typename R, bool WIDE>
 static hipError_t launch_first_hit_t(const FirstHitArgs& a, const void* cam, uint32_t blocks, int threads,
                                      uint32_t lds_bytes, hipStream_t stream) {
-  hipError_t e = allow_big_lds(first_hit_kernel<R, WIDE>, lds_bytes);
+  if (lds_bytes > LDS_LIMIT_BYTES) return hipErrorInvalidValue;
+  hipError_t e = allow_big_lds(first_hit_kernel<R, WIDE>, LDS_LIMIT_BYTES);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((first_hit_kernel<R, WIDE>), dim3(blocks), dim3(threads), lds_bytes, stream, a,
                      *static_cast<const CamDev<R>*>(cam));
@@ -1381,6 +1398,13 @@ hipError_t launch_first_hit(int precision, const FirstHitArgs& a, const void* ca
 hipError_t launch_accum_add(long long* dst, const long long* src, size_t n, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(accum_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, src, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_accum_add_many(long long* dst, const long long* src, size_t n, int count, hipStream_t stream) {
+  if (n == 0 || count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(accum_add_many_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, src, n,
+                     count);
   return hipGetLastError();
 }
 

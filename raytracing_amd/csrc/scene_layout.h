@@ -78,8 +78,10 @@ constexpr uint32_t MAX_TEXTURES = 1u << 15;
 // material word 0: kind | texture << 4 ; word 1 (R) : parameter
 // texture record R4: data[0..2], word 3 low 32 bits: kind | child0 << 2 | child1 << 17
 
-// node: the bounds of the two children, lo0.xyz hi0.xyz lo1.xyz hi1.xyz, then the child
-// references.
+// node: the bounds of the two children, per axis four numbers, one pair for each child
+//   R = double: x: lo0 lo1 hi0 hi1, then y, then z
+//   R = float : x: centre0 centre1 half0 half1, then y, then z (half-extents rounded up)
+// then the child references.
 //   on-chip store: 12 R, then one u32 c0 | c1 << 16            (float 64 B, double 112 B)
 //   HBM store, R = double: 12 doubles, then two u32             (112 B)
 //   HBM store, R = float : 12 IEEE half floats rounded OUTWARD, then two u32 (32 B).

@@ -21,6 +21,39 @@ def hip():
     return _hip
 
 
+class RawBuffer:
+    """A device allocation of `nbytes` bytes filled with `fill`, read back as any dtype."""
+
+    def __init__(self, nbytes: int, fill: int = 0):
+        self.nbytes = nbytes
+        self.ptr = C.c_void_p()
+        assert hip().hipMalloc(C.byref(self.ptr), nbytes) == 0
+        assert hip().hipMemset(self.ptr, fill, nbytes) == 0
+        assert hip().hipDeviceSynchronize() == 0
+
+    @property
+    def address(self) -> int:
+        return self.ptr.value
+
+    def to_host(self, dtype, shape) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        assert hip().hipDeviceSynchronize() == 0
+        assert hip().hipMemcpy(out.ctypes.data_as(C.c_void_p), self.ptr, out.nbytes, 2) == 0  # D2H
+        return out
+
+    def free(self):
+        if self.ptr:
+            hip().hipFree(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class DeviceBuffer:
     """A zero-initialised int64 device array (radiance sums, 32.32 fixed point)."""
 

@@ -254,13 +254,32 @@ def test_error_handling(dev, flat_scene):
 
 
 def test_cancel(dev, flat_scene):
+    """shouldBreak of the reference stops the frame in flight only (main.scala:80)."""
+    import threading
+
     cam, flat, s = gpu_scene(dev, flat_scene, "scene")
+    # a request that arrives while nothing renders belongs to no frame: the next frame runs
     s.cancel()
-    with pytest.raises(dev.HipTraceError) as e:
-        s.render(cam, 64, 36, 8, batch=1)
-    assert e.value.code == A.HT_E_CANCELLED
-    out = s.render(cam, 64, 36, 2)  # the flag is consumed; the next frame renders
+    out = s.render(cam, 64, 36, 2)
     assert out["stats"]["samples"] == 64 * 36 * 2
+    # a request from another thread stops a running frame at the next batch boundary, and
+    # the frame holds exactly the samples it reports
+    W, H, asked = 256, 144, 200000  # tens of seconds of work if nothing stopped it
+    with dev.Frame(s, W, H) as f:
+        timer = threading.Timer(0.05, s.cancel)
+        timer.start()
+        with pytest.raises(dev.HipTraceError) as e:
+            f.accumulate(cam, asked, batch=1, seed=1)
+        timer.join()
+        assert e.value.code == A.HT_E_CANCELLED
+        got = f.samples
+        assert 0 < got < asked
+        part = f.read()["packed"]
+    np.testing.assert_array_equal(part, s.render(cam, W, H, got, seed=1)["packed"])
+    # offsets past the 31-bit sample index are refused, not wrapped
+    with pytest.raises(dev.HipTraceError) as e:
+        s.render(cam, 16, 16, 2, sample_offset=2 ** 31 - 2)
+    assert e.value.code == A.HT_E_INVALID
 
 
 def test_render_frame_mirror(dev, flat_scene):
