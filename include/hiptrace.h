@@ -206,6 +206,27 @@ int ht_render(ht_scene* scene, const ht_camera* camera, const ht_render_params* 
  * launches, calls or GPUs. */
 #define HT_ACCUM_ONE 4294967296.0
 
+/* An entry point that allocates nothing.  It has no counterpart in the reference; it is for
+ * callers that cannot allocate device memory or wait on the device: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  The same frame as
+ * ht_render (same kernels, same sums), with these differences:
+ *   - rgb_linear_dev / rgb_packed_dev are DEVICE buffers on the scene's device (layouts as in
+ *     ht_render; either may be NULL);
+ *   - all work is enqueued on `stream` (a hipStream_t, NULL: default stream) and the call
+ *     returns without waiting for it; there are no statistics and no cancel point;
+ *   - the radiance sums and the work-queue heads live in a static device array of the
+ *     library (48 MiB + 4 KiB that every GPU the library has run on holds until the process
+ *     ends), so width * height may not exceed HT_NOALLOC_MAX_PIXELS (HT_E_TOO_LARGE);
+ *   - the call makes no hipMalloc / hipFree and no allocating library call (error
+ *     messages go to a fixed per-thread buffer).
+ * Every call on one GPU uses that GPU's one array: calls that overlap in time on the same
+ * GPU (two streams, two threads, two scene handles) race and give wrong pictures; order
+ * them on one stream or with events.  The array keeps the last call's sums; each call
+ * clears the part it uses on `stream` before rendering into it. */
+#define HT_NOALLOC_MAX_PIXELS (1 << 21) /* 2 097 152 >= 1920 x 1080 */
+int ht_render_noalloc(ht_scene* scene, const ht_camera* camera, const ht_render_params* params,
+                      float* rgb_linear_dev, uint32_t* rgb_packed_dev, void* stream);
+
 /* Multi-device building block: add this call's radiance SUMS (not means) into
  * `accum_dev`, a DEVICE buffer of width*height*3 int64 on the scene's device
  * (row 0 = bottom; the caller zeroes it before the first call).  `stream` is a

@@ -12,6 +12,7 @@ HT_TEX_SOLID, HT_TEX_CHECKER, HT_TEX_PERLIN, HT_TEX_IMAGE = range(4)
 HT_TEX_STRIDE = 4
 HT_PERLIN_POINTS = 256
 HT_PRECISION_FP32, HT_PRECISION_FP64 = 0, 1
+HT_NOALLOC_MAX_PIXELS = 1 << 21
 
 _pi32 = C.POINTER(C.c_int32)
 _pi64 = C.POINTER(C.c_int64)
@@ -134,6 +135,7 @@ EXPORTS = [
     "ht_scene_create",
     "ht_scene_destroy",
     "ht_render",
+    "ht_render_noalloc",
     "ht_render_accumulate", "ht_render_sharded",
     "ht_resolve",
     "ht_resolve_device",

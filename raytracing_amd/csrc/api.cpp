@@ -487,11 +487,19 @@ int ht_scene_create(const ht_scene_desc* desc, int device, ht_scene** out) {
     ht_scene_destroy(s);
     return fail(HT_E_HIP, "device allocation / upload failed: %s", hipGetErrorString(e));
   }
-  // the launch shapes of the two production variants, so that no render call pays for them
+  // Set-up for the entry point that may not allocate or query later on: the launch shapes of
+  // the two production variants and this device's address of the static scratch array.
   {
     LaunchShape sh;
     (void)launch_shape(s, HT_PRECISION_FP32, false, sh);  // a scene too large for a variant fails when rendered
     (void)launch_shape(s, HT_PRECISION_FP64, false, sh);
+    void* scratch = nullptr;
+    e = static_scratch(device, &scratch);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      ht_scene_destroy(s);
+      return fail(HT_E_HIP, "hipGetSymbolAddress of the static scratch array failed: %s", hipGetErrorString(e));
+    }
   }
   *out = s;
   return HT_OK;
@@ -606,6 +614,42 @@ int ht_render(ht_scene* s, const ht_camera* cam, const ht_render_params* p, floa
   }
   return rc;
   HT_API_CATCH
+}
+
+int ht_render_noalloc(ht_scene* s, const ht_camera* cam, const ht_render_params* p, float* rgb_linear_dev,
+                      uint32_t* rgb_packed_dev, void* stream_v) {
+  if (!s || !p) return fail(HT_E_INVALID, "NULL argument");
+  int rc = check_camera(cam);
+  if (rc != HT_OK) return rc;
+  rc = check_params(s, p);
+  if (rc != HT_OK) return rc;
+  if (p->collect_counters) return fail(HT_E_INVALID, "ht_render_noalloc does not collect counters");
+  const int64_t pixels = (int64_t)p->width * p->height;
+  if (pixels > (int64_t)HT_NOALLOC_MAX_PIXELS)
+    return fail(HT_E_TOO_LARGE, "ht_render_noalloc: %d x %d = %lld pixels, the static scratch array holds %d",
+                p->width, p->height, (long long)pixels, HT_NOALLOC_MAX_PIXELS);
+  hipStream_t stream = (hipStream_t)stream_v;
+  DeviceGuard g(s->device);
+  if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
+  // this device's copy of the static array: [radiance sums of HT_NOALLOC_MAX_PIXELS pixels][queue heads]
+  void* scratch = nullptr;
+  HIP_TRY(static_scratch(s->device, &scratch));
+  int64_t* sums = (int64_t*)scratch;
+  uint8_t* heads = (uint8_t*)scratch + (size_t)HT_NOALLOC_MAX_PIXELS * 3 * sizeof(int64_t);
+
+  RenderPlan pl;
+  rc = make_plan(s, cam, p, sums, pl);  // launch shape: cached since ht_scene_create
+  if (rc != HT_OK) return rc;
+  // the array keeps the last call's sums: clear what this call adds to
+  HIP_TRY(hipMemsetAsync(sums, 0, (size_t)pixels * 3 * sizeof(int64_t), stream));
+  int k = 0;
+  for (int done = 0; done < p->samples; done += pl.batch, ++k) {
+    uint32_t* head = (uint32_t*)(heads + (size_t)(k % (int)STATIC_QUEUE_SLOTS) * QUEUE_SLOT_BYTES);
+    HIP_TRY(enqueue_launch(pl, head, p->sample_offset + done, std::min(pl.batch, p->samples - done), stream));
+  }
+  HIP_TRY(launch_resolve((const long long*)sums, p->width, p->height, 1.0 / (double)p->samples, rgb_linear_dev,
+                         rgb_packed_dev, stream));
+  return HT_OK;
 }
 
 int ht_render_sharded(ht_scene* const* scenes, int32_t n, const ht_camera* cam, const ht_render_params* p,

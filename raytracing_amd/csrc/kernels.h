@@ -80,6 +80,12 @@ hipError_t launch_first_hit(int precision, const FirstHitArgs& a, const void* ca
 hipError_t launch_accum_add(long long* dst, const long long* src, size_t n, hipStream_t stream);
 // dst[i] += sum over j < count of src[j * n + i]: the other shards' copies of one slice of the frame
 hipError_t launch_accum_add_many(long long* dst, const long long* src, size_t n, int count, hipStream_t stream);
+
+// The library's static device array (see kernels.hip): the address of the current device's
+// copy, looked up once per device.  Layout: radiance sums of HT_NOALLOC_MAX_PIXELS pixels
+// (3 x int64 each), then STATIC_QUEUE_SLOTS work-queue heads of 256 bytes.
+constexpr uint32_t STATIC_QUEUE_SLOTS = 16;
+hipError_t static_scratch(int device, void** out);
 // mean + Vec3.toRGB + row flip (Vec3.scala:82-84, main.scala:93)
 hipError_t launch_resolve(const long long* accum, int32_t W, int32_t H, double inv_samples,
                           float* rgb_mean, uint32_t* rgb_packed, hipStream_t stream);

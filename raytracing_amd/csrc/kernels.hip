@@ -36,6 +36,9 @@
 //  the reference.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
+#include "../../include/hiptrace.h"
 #include "kernels.h"
 
 namespace ht {
@@ -1299,6 +1302,39 @@ __global__ void accum_add_many_kernel(long long* __restrict__ dst, const long lo
   long long v = dst[i];
   for (int j = 0; j < count; ++j) v += src[(size_t)j * n + i];
   dst[i] = v;
+}
+
+// ---------------------------------------------------------------------------
+// static scratch array (ht_render_noalloc)
+// ---------------------------------------------------------------------------
+// Device memory for callers that may not allocate: the radiance sums of one frame of up to
+// HT_NOALLOC_MAX_PIXELS pixels and a ring of work-queue heads.  Every GPU the library runs
+// on holds its own copy (48 MiB + 4 KiB) from the moment the code object is loaded until the
+// process ends.  In host code the name `scratch` is only a handle for hipGetSymbolAddress:
+// kernels, memsets and copies get the per-device address that static_scratch() returns.
+constexpr size_t STATIC_SCRATCH_BYTES =
+    (size_t)HT_NOALLOC_MAX_PIXELS * 3u * sizeof(long long) + (size_t)STATIC_QUEUE_SLOTS * 256u;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
+hipError_t static_scratch(int device, void** out) {
+  constexpr int MAX_DEVICES = 64;
+  static std::mutex mu;
+  static void* ptr[MAX_DEVICES];  // zero-initialised: not looked up yet
+  *out = nullptr;
+  if (device < 0 || device >= MAX_DEVICES) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ptr[device]) {
+    int cur = -1;
+    hipError_t e = hipGetDevice(&cur);
+    if (e != hipSuccess) return e;
+    if (cur != device) return hipErrorInvalidDevice;  // the caller makes `device` current first
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    ptr[device] = p;
+  }
+  *out = ptr[device];
+  return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------

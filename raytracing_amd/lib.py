@@ -46,6 +46,7 @@ def load() -> C.CDLL:
     L.ht_scene_destroy.restype = None
     L.ht_render.argtypes = [vp, C.POINTER(A.ht_camera), C.POINTER(A.ht_render_params), A._pf32, A._pu32,
                             C.POINTER(A.ht_stats)]
+    L.ht_render_noalloc.argtypes = [vp, C.POINTER(A.ht_camera), C.POINTER(A.ht_render_params), vp, vp, vp]
     L.ht_render_accumulate.argtypes = [vp, C.POINTER(A.ht_camera), C.POINTER(A.ht_render_params), vp, vp,
                                        C.POINTER(A.ht_stats)]
     L.ht_render_sharded.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(A.ht_camera), C.POINTER(A.ht_render_params),
@@ -145,6 +146,13 @@ class Scene:
         _check(load().ht_render(self._h, C.byref(cc), C.byref(p), rgb.ctypes.data_as(A._pf32),
                                 packed.ctypes.data_as(A._pu32), C.byref(st)))
         return {"rgb": rgb, "packed": packed, "stats": st.as_dict()}
+
+    def render_noalloc(self, camera, params: A.ht_render_params, rgb_ptr: int, packed_ptr: int, stream: int = 0):
+        """ht_render_noalloc: the frame of ht_render into DEVICE buffers (addresses as int,
+        0 = skip), enqueued on `stream`; the sums live in the library's static array."""
+        cc = camera.to_c()
+        _check(load().ht_render_noalloc(self._h, C.byref(cc), C.byref(params), C.c_void_p(rgb_ptr),
+                                        C.c_void_p(packed_ptr), C.c_void_p(stream)))
 
     def render_accumulate(self, camera, params: A.ht_render_params, accum_ptr: int, stream: int = 0,
                           want_stats: bool = True) -> Optional[dict]:
