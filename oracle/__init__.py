@@ -50,6 +50,7 @@ def lib():
         L.or_scene_destroy.restype = None
         L.or_first_hit.argtypes = [C.c_void_p, C.POINTER(A.ht_camera), C.c_int32, C.c_int32, C.c_int,
                                    C.c_double, C.c_double, pd, pi, pd, pd]
+        L.or_first_hit_fp32_rays.argtypes = L.or_first_hit.argtypes
         L.or_render.argtypes = [C.c_void_p, C.POINTER(A.ht_camera), C.c_int32, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_int32, C.c_int32, C.c_int, C.c_int, C.c_uint64, C.c_int,
                                 pd, pu, C.POINTER(or_counters)]
@@ -134,14 +135,16 @@ class OracleScene:
         lib().or_bvh_stats(self._h, C.byref(n), C.byref(d))
         return n.value, d.value
 
-    def first_hit(self, camera, W, H, world_mode=OR_WORLD_REFERENCE_BVH, off=(0.5, 0.5)):
+    def first_hit(self, camera, W, H, world_mode=OR_WORLD_REFERENCE_BVH, off=(0.5, 0.5), fp32_rays=False):
+        """fp32_rays: round every camera ray (origin, direction) to fp32 before the fp64 trace."""
         t = np.zeros((H, W))
         pid = np.zeros((H, W), dtype=np.int32)
         n = np.zeros((H, W, 3))
         uv = np.zeros((H, W, 2))
         cc = camera.to_c()
-        rc = lib().or_first_hit(self._h, C.byref(cc), W, H, world_mode, off[0], off[1], _pd(t),
-                                pid.ctypes.data_as(A._pi32), _pd(n), _pd(uv))
+        fn = lib().or_first_hit_fp32_rays if fp32_rays else lib().or_first_hit
+        rc = fn(self._h, C.byref(cc), W, H, world_mode, off[0], off[1], _pd(t),
+                pid.ctypes.data_as(A._pi32), _pd(n), _pd(uv))
         if rc != 0:
             raise RuntimeError(f"or_first_hit failed: {rc}")
         return {"t": t, "prim_id": pid, "normal": n, "uv": uv}

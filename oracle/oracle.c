@@ -920,9 +920,9 @@ int or_path_radiance(const or_scene* s, const ht_camera* cam_in, int32_t W, int3
   return HT_OK;
 }
 
-int or_first_hit(const or_scene* s, const ht_camera* cam_in, int32_t W, int32_t H, int world_mode,
-                 double off_x, double off_y, double* t, int32_t* prim_id, double* normal,
-                 double* uv) {
+static int first_hit_impl(const or_scene* s, const ht_camera* cam_in, int32_t W, int32_t H, int world_mode,
+                          double off_x, double off_y, int round_ray_fp32, double* t, int32_t* prim_id,
+                          double* normal, double* uv) {
   if (!s || !cam_in || W < 2 || H < 2) return HT_E_INVALID;
   camera_t cam;
   camera_init(&cam, cam_in);
@@ -933,6 +933,10 @@ int or_first_hit(const or_scene* s, const ht_camera* cam_in, int32_t W, int32_t 
       double u = (i + off_x) / (W - 1);
       double v = (j + off_y) / (H - 1);
       ray_t r = camera_ray(&cam, u, v, V(0, 0, 0));
+      if (round_ray_fp32) {  /* the ray an fp32 device can at best hold: each component to the nearest float */
+        r.o = V((float)r.o.x, (float)r.o.y, (float)r.o.z);
+        r.d = V((float)r.d.x, (float)r.d.y, (float)r.d.z);
+      }
       hit_t hit;
       size_t p = (size_t)j * W + i;
       if (world_hit(s, world_mode, &r, 0.001, INFINITY, &hit, NULL)) {
@@ -949,6 +953,21 @@ int or_first_hit(const or_scene* s, const ht_camera* cam_in, int32_t W, int32_t 
       }
     }
   return HT_OK;
+}
+
+int or_first_hit(const or_scene* s, const ht_camera* cam_in, int32_t W, int32_t H, int world_mode,
+                 double off_x, double off_y, double* t, int32_t* prim_id, double* normal,
+                 double* uv) {
+  return first_hit_impl(s, cam_in, W, H, world_mode, off_x, off_y, 0, t, prim_id, normal, uv);
+}
+
+/* The same query for camera rays whose origin and direction were rounded to fp32 first and
+ * then traced in fp64: what separates "the device computes badly" from "a ray held in fp32
+ * is not the reference's ray" when the fp32 device path is compared with this restatement. */
+int or_first_hit_fp32_rays(const or_scene* s, const ht_camera* cam_in, int32_t W, int32_t H, int world_mode,
+                           double off_x, double off_y, double* t, int32_t* prim_id, double* normal,
+                           double* uv) {
+  return first_hit_impl(s, cam_in, W, H, world_mode, off_x, off_y, 1, t, prim_id, normal, uv);
 }
 
 /* ---------------- probes for known-answer tests ---------------- */

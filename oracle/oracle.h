@@ -68,6 +68,11 @@ void or_scene_destroy(or_scene* s);
 int or_first_hit(const or_scene* s, const ht_camera* cam, int32_t W, int32_t H, int world_mode,
                  double off_x, double off_y, double* t, int32_t* prim_id, double* normal,
                  double* uv);
+/* or_first_hit for camera rays rounded to fp32 (origin and direction, component-wise to the
+ * nearest float) before the fp64 trace: the best an fp32 ray can do. */
+int or_first_hit_fp32_rays(const or_scene* s, const ht_camera* cam, int32_t W, int32_t H, int world_mode,
+                           double off_x, double off_y, double* t, int32_t* prim_id, double* normal,
+                           double* uv);
 
 /* renderFrame (main.scala:79-94).  rgb_linear [W*H*3] = mean radiance, row 0 =
  * bottom; rgb_packed [W*H] = toRGB codes, row 0 = top (BufferedImage order).

@@ -125,7 +125,7 @@ template <typename R>
 void fill_cam(const CameraBasis& b, CamDev<R>& c) {
   for (int i = 0; i < 3; ++i) {
     c.origin[i] = (R)b.origin[i];
-    c.llc[i] = (R)b.llc[i];
+    c.corner[i] = (R)(b.llc[i] - b.origin[i]);
     c.horizontal[i] = (R)b.horizontal[i];
     c.vertical[i] = (R)b.vertical[i];
     c.u[i] = (R)b.u[i];

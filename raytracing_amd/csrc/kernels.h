@@ -9,9 +9,13 @@ namespace ht {
 
 // Camera basis of Camera.scala:5-17 (reference), computed on the host in fp64
 // and rounded to the kernel's arithmetic type.
+// corner = lower_left_corner - origin, subtracted in fp64 before the rounding: a ray
+// direction is corner + s*horizontal + t*vertical - lens offset, two fused multiply-adds per
+// component, and carries about one ulp of error instead of the three of the reference's
+// order of operations in fp32.
 template <typename R>
 struct CamDev {
-  R origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3], background[3];
+  R origin[3], corner[3], horizontal[3], vertical[3], u[3], v[3], background[3];
   R lens_radius;
 };
 

@@ -878,7 +878,7 @@ __device__ __forceinline__ void camera_ray(const RenderArgs& A, CamPtr camp, Ray
   R t = ((R)j + xi2) / (R)(A.H - 1);
   V3<R> origin = ld3<R>(cam.origin);
   ray.o = origin + offset;
-  ray.d = ld3<R>(cam.llc) + s * ld3<R>(cam.horizontal) + t * ld3<R>(cam.vertical) - origin - offset;
+  ray.d = (ld3<R>(cam.corner) + s * ld3<R>(cam.horizontal) + t * ld3<R>(cam.vertical)) - offset;
 }
 
 // The camera of render_kernel, read from the kernel-argument segment where it is used.

@@ -15,7 +15,8 @@ import numpy as np
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhiptrace.so")
+# HIPTRACE_LIB: another build of the same library (A/B measurements); default: the in-tree build
+LIB_PATH = os.environ.get("HIPTRACE_LIB") or os.path.join(_HERE, "libhiptrace.so")
 
 
 class HipTraceError(RuntimeError):

@@ -123,7 +123,9 @@ def test_large_mesh_first_hit_fp32_matches_oracle(dev, oracle_mod, mesh20k):
     hit = stable & (o["prim_id"] >= 0)
     rel = np.abs(g["t"][hit].astype(np.float64) - o["t"][hit]) / np.abs(o["t"][hit])
     assert np.all(rel <= 1e-5 + 8 * sens[hit])
-    assert (rel <= 1e-5).mean() >= 0.97
+    inside = float((rel <= 1e-5).mean())
+    print(f"20k-triangle mesh: t inside the plain 1e-5 on {inside:.5f} of the stable hit pixels (max {rel.max():.2e})")
+    assert inside >= 0.999
 
 
 def test_large_mesh_matched_render(dev, oracle_mod, mesh20k):

@@ -8,7 +8,13 @@ Tolerances
     own answer is stable under a ~1 ulp perturbation of the ray; t and normal within
     1e-5 relative, widened per pixel by 8x the oracle's sensitivity to that same
     perturbation (a ray stored in fp32 is only defined to ~1e-7 relative, and grazing
-    hits amplify that); at least 97 % of the hit pixels meet the plain 1e-5.
+    hits amplify that).  The share of hit pixels inside the PLAIN 1e-5 is printed and
+    asserted per scene: >= 99.9 % for t on every scene, >= 99.9 % for normals on every
+    scene but random.json (>= 99.4 %).  random.json is the one scene where fp32 rays cannot
+    do better: its 0.2-radius spheres stand 10-25 units from the camera, so the 2^-24
+    rounding of a ray direction moves the hit point by ~1.5e-6 and the normal by ~1e-5;
+    the oracle itself, fed camera rays rounded to fp32 and tracing them in fp64, leaves
+    0.11 % of that scene's normals outside 1e-5 (tests/test_oracle_kat.py pins that floor).
   * matched-stream renders (same Philox-keyed paths on both sides): >= 99 % of the
     pixels within 2e-3 absolute and PSNR >= 45 dB on the 8-bit toRGB codes; the rest
     are paths where fp32 rounding flipped a discrete decision.
@@ -94,7 +100,13 @@ def test_first_hit_fp32_matches_oracle(dev, oracle_mod, flat_scene, name):
     assert np.all(terr <= 1e-5 + 8 * sens_t[ok]), f"t error {terr.max():.3e}"
     assert np.all(nerr <= 1e-5 + 8 * sens_n[ok]), f"normal error {nerr.max():.3e}"
     if ok.any():
-        assert (terr <= 1e-5).mean() >= 0.97 and (nerr <= 1e-5).mean() >= 0.97
+        t_in, n_in = float((terr <= 1e-5).mean()), float((nerr <= 1e-5).mean())
+        print(f"{name}: inside the plain 1e-5: t {t_in:.5f} (max {terr.max():.2e}), "
+              f"normal {n_in:.5f} (max {nerr.max():.2e}, p99.9 {np.percentile(nerr, 99.9):.2e}); "
+              f"ids differ on {int(mism.sum())} unstable pixels")
+        assert t_in >= 0.999, f"{name}: {1 - t_in:.2e} of the hit pixels have t outside 1e-5"
+        floor = 0.994 if name == "random" else 0.999
+        assert n_in >= floor, f"{name}: {1 - n_in:.2e} of the hit pixels have the normal outside 1e-5"
     # misses are +inf / -1 / zero normal
     miss = ~hit & ~mism
     assert np.all(np.isinf(g["t"][miss])) and np.all(g["normal"][miss] == 0)
@@ -169,6 +181,49 @@ def test_converged_image_vs_reference_sampler(dev, oracle_mod, flat_scene):
     noise = np.sqrt(((ref_a - ref_b) ** 2).mean())
     diff = np.sqrt(((ref_a - g) ** 2).mean())
     assert 0.75 < diff / noise < 1.33
+
+
+def _codes_of(rgb):
+    """Vec3.toRGB per channel (Vec3.scala:82-84) of linear means, as floats 0..254."""
+    return np.floor(255.0 * np.clip(np.sqrt(np.maximum(rgb, 0.0)), 0.0, 0.999))
+
+
+def _psnr(a, b):
+    mse = ((a - b) ** 2).mean()
+    return 99.0 if mse == 0 else float(10 * np.log10(255.0 ** 2 / mse))
+
+
+@pytest.mark.parametrize("name,W,H,spp,bin_", [("dragon", 160, 90, 320, 1), ("random", 160, 90, 640, 1),
+                                                ("cornell", 128, 128, 1024, 8)])
+def test_converged_image_psnr_vs_reference_sampler(dev, oracle_mod, flat_scene, name, W, H, spp, bin_):
+    """The converged-image gate on the headline scenes: device (fp32, Philox, direct
+    sampling) against the oracle running the reference's own rejection samplers
+    (main.scala:87-93, Vec3.scala:17-34) at matched spp, PSNR on the 8-bit toRGB codes.
+    Two independent Monte-Carlo renders differ by noise, so the gate has two parts: the
+    spp is high enough that two oracle renders with different seeds agree to >= 40 dB
+    (the noise floor, asserted and printed), and the device is >= 40 dB from the oracle
+    and no further from it than that floor minus 1 dB; a bias of about one 8-bit code
+    anywhere in the picture would cost more than that.  The Cornell box (small light, no next-event
+    estimation in the reference) has per-pixel noise far above 40 dB at any spp a CPU can
+    render, so its pictures are compared after averaging 8x8 pixel blocks of linear
+    radiance."""
+    cam, flat, s = gpu_scene(dev, flat_scene, name)
+    osc = oracle_mod.OracleScene(flat, bvh_seed=1)
+    ref_a = osc.render(cam, W, H, spp, sampler=oracle_mod.OR_SAMPLER_REFERENCE, seed=1)["rgb"]
+    ref_b = osc.render(cam, W, H, spp, sampler=oracle_mod.OR_SAMPLER_REFERENCE, seed=2)["rgb"]
+    g = s.render(cam, W, H, spp, seed=3)["rgb"].astype(np.float64)
+
+    def picture(rgb):
+        if bin_ > 1:
+            rgb = rgb.reshape(H // bin_, bin_, W // bin_, bin_, 3).mean(axis=(1, 3))
+        return _codes_of(rgb)
+
+    floor = _psnr(picture(ref_a), picture(ref_b))
+    got = min(_psnr(picture(ref_a), picture(g)), _psnr(picture(ref_b), picture(g)))
+    print(f"{name} {W}x{H} {spp} spp (bin {bin_}): oracle two-seed PSNR {floor:.2f} dB, device vs oracle {got:.2f} dB")
+    assert floor >= 40.0, f"{name}: the oracle's own two-seed PSNR is {floor:.2f} dB; raise spp"
+    assert got >= 40.0, f"{name}: device vs oracle {got:.2f} dB (noise floor {floor:.2f} dB)"
+    assert got >= floor - 1.0, f"{name}: device vs oracle {got:.2f} dB, noise floor {floor:.2f} dB"
 
 
 # ---- properties at the benchmark's full sizes ---------------------------------------------------

@@ -32,7 +32,8 @@ for name in names:
     good = both & stable & (sens <= 2.5e-6)
     print(f"{name:8s} hits={hit.sum()} id_mismatch={idm.sum()} (on stable: {(idm & stable).sum()}) unstable={(~stable).sum()} illcond={(hit & (sens > 2.5e-6)).sum()} "
           f"t: max_all={terr.max():.2e} max_good={terr[good].max() if good.any() else 0:.2e} p99.9={np.percentile(terr[both], 99.9):.2e} "
-          f"n: max_all={nerr.max():.2e} max_good={nerr[good].max() if good.any() else 0:.2e} p99.9={np.percentile(nerr[both], 99.9):.2e}", flush=True)
+          f"n: max_all={nerr.max():.2e} max_good={nerr[good].max() if good.any() else 0:.2e} p99.9={np.percentile(nerr[both], 99.9):.2e} "
+          f"outside 1e-5: t {(terr[both] > 1e-5).mean():.2e} n {(nerr[both] > 1e-5).mean():.2e}", flush=True)
     # worst good pixels
     idx = np.argsort((nerr * good).ravel())[-3:]
     for k in idx:
