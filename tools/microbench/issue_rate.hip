@@ -11,8 +11,8 @@
 #define REP8(x) x x x x x x x x
 #define CHK(c) do { hipError_t e_ = (c); if (e_ != hipSuccess) { printf("%s: %s\n", #c, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum Kind { K_ADD, K_FMA, K_PKADD, K_PKFMA, K_MAD64, K_MULLO, K_MIN3, K_CNDMASK, K_CMP, K_RCP, K_SQRT, K_SALU, K_ADD_SALU, K_DSREAD, K_CVT, K_MUL, K_MAX, K_AND, K_CND64, K_CMPCND, K_MIN, K_SUB, K_LSHLADD, K_MED3, K_NKINDS };
-static const char* names[] = {"v_add_f32", "v_fma_f32", "v_pk_add_f32", "v_pk_fma_f32", "v_mad_u64_u32", "v_mul_lo_u32", "v_min3_f32", "v_cndmask_b32", "v_cmp_lt_f32", "v_rcp_f32", "v_sqrt_f32", "s_add_u32", "v_add+s_add pairs", "ds_read_b128", "v_cvt_f32_f16", "v_mul_f32", "v_max_f32", "v_and_b32", "v_cndmask_e64 sgpr", "v_cmp+v_cndmask", "v_min_f32", "v_sub_f32", "v_lshl_add_u32", "v_med3_f32"};
+enum Kind { K_ADD, K_FMA, K_PKADD, K_PKFMA, K_MAD64, K_MULLO, K_MIN3, K_CNDMASK, K_CMP, K_RCP, K_SQRT, K_SALU, K_ADD_SALU, K_DSREAD, K_CVT, K_MUL, K_MAX, K_AND, K_CND64, K_CMPCND, K_MIN, K_SUB, K_LSHLADD, K_MED3, K_FMAC, K_FMA_ABC, K_FMA_ACC, K_NKINDS };
+static const char* names[] = {"v_add_f32", "v_fma_f32", "v_pk_add_f32", "v_pk_fma_f32", "v_mad_u64_u32", "v_mul_lo_u32", "v_min3_f32", "v_cndmask_b32", "v_cmp_lt_f32", "v_rcp_f32", "v_sqrt_f32", "s_add_u32", "v_add+s_add pairs", "ds_read_b128", "v_cvt_f32_f16", "v_mul_f32", "v_max_f32", "v_and_b32", "v_cndmask_e64 sgpr", "v_cmp+v_cndmask", "v_min_f32", "v_sub_f32", "v_lshl_add_u32", "v_med3_f32", "v_fmac_f32 a,b,c", "v_fma_f32 a,a,b,c", "v_fma_f32 a,b,c,a"};
 
 template <int K>
 __global__ void __launch_bounds__(1024) probe(uint64_t* out, int iters, uint64_t mask, float seed) {
@@ -27,8 +27,9 @@ __global__ void __launch_bounds__(1024) probe(uint64_t* out, int iters, uint64_t
   uint32_t s0 = 1, s1 = 2, s2 = 3, s3 = 4;
   const uint32_t addr = (threadIdx.x & 63u) * 16u;
   const bool on = (mask >> (threadIdx.x & 63u)) & 1ull;
-  uint64_t t0 = 0, t1 = 0;
+  uint64_t t0 = 0, t1 = 0, r0 = 0;
   if (on) {  // the exec mask under test
+    r0 = __builtin_amdgcn_s_memrealtime();
     t0 = __builtin_amdgcn_s_memtime();
     for (int i = 0; i < iters; ++i) {
       if (K == K_ADD) { REP8(asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0));) }
@@ -42,6 +43,9 @@ __global__ void __launch_bounds__(1024) probe(uint64_t* out, int iters, uint64_t
       if (K == K_LSHLADD) { REP8(asm volatile("v_lshl_add_u32 %0, %0, 1, %8\n v_lshl_add_u32 %1, %1, 1, %8\n v_lshl_add_u32 %2, %2, 1, %8\n v_lshl_add_u32 %3, %3, 1, %8\n v_lshl_add_u32 %4, %4, 1, %8\n v_lshl_add_u32 %5, %5, 1, %8\n v_lshl_add_u32 %6, %6, 1, %8\n v_lshl_add_u32 %7, %7, 1, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0));) }
       if (K == K_MED3) { REP8(asm volatile("v_med3_f32 %0, %0, %8, %1\n v_med3_f32 %1, %1, %8, %2\n v_med3_f32 %2, %2, %8, %3\n v_med3_f32 %3, %3, %8, %4\n v_med3_f32 %4, %4, %8, %5\n v_med3_f32 %5, %5, %8, %6\n v_med3_f32 %6, %6, %8, %7\n v_med3_f32 %7, %7, %8, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0));) }
       if (K == K_FMA) { REP8(asm volatile("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0));) }
+      if (K == K_FMAC) { REP8(asm volatile("v_fmac_f32 %0, %8, %9\n v_fmac_f32 %1, %8, %9\n v_fmac_f32 %2, %8, %9\n v_fmac_f32 %3, %8, %9\n v_fmac_f32 %4, %8, %9\n v_fmac_f32 %5, %8, %9\n v_fmac_f32 %6, %8, %9\n v_fmac_f32 %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(b1));) }
+      if (K == K_FMA_ABC) { REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(b1));) }
+      if (K == K_FMA_ACC) { REP8(asm volatile("v_fma_f32 %0, %8, %9, %0\n v_fma_f32 %1, %8, %9, %1\n v_fma_f32 %2, %8, %9, %2\n v_fma_f32 %3, %8, %9, %3\n v_fma_f32 %4, %8, %9, %4\n v_fma_f32 %5, %8, %9, %5\n v_fma_f32 %6, %8, %9, %6\n v_fma_f32 %7, %8, %9, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(b1));) }
       if (K == K_MIN3) { REP8(asm volatile("v_min3_f32 %0, %0, %8, %1\n v_min3_f32 %1, %1, %8, %2\n v_min3_f32 %2, %2, %8, %3\n v_min3_f32 %3, %3, %8, %4\n v_min3_f32 %4, %4, %8, %5\n v_min3_f32 %5, %5, %8, %6\n v_min3_f32 %6, %6, %8, %7\n v_min3_f32 %7, %7, %8, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0));) }
       if (K == K_CNDMASK) { REP8(asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0) : "vcc");) }
       if (K == K_CMP) { REP8(asm volatile("v_cmp_lt_f32 vcc, %0, %8\n v_cmp_lt_f32 vcc, %1, %8\n v_cmp_lt_f32 vcc, %2, %8\n v_cmp_lt_f32 vcc, %3, %8\n v_cmp_lt_f32 vcc, %4, %8\n v_cmp_lt_f32 vcc, %5, %8\n v_cmp_lt_f32 vcc, %6, %8\n v_cmp_lt_f32 vcc, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0) : "vcc");) }
@@ -70,13 +74,16 @@ __global__ void __launch_bounds__(1024) probe(uint64_t* out, int iters, uint64_t
   }
   float sum = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(s0 + s1 + s2 + s3);
   if (sum == 123.456f) out[3] = 1;  // keep the chains alive
-  if (blockIdx.x == 0 && threadIdx.x == (uint32_t)__builtin_ctzll(mask)) out[0] = t1 - t0;
+  if (blockIdx.x == 0 && threadIdx.x == (uint32_t)__builtin_ctzll(mask)) {
+    out[0] = t1 - t0;
+    out[1] = __builtin_amdgcn_s_memrealtime() - r0;  // 100 MHz ticks over the same span
+  }
 }
 
 template <int K>
 static void run_kind(uint64_t* d_out, int wps, uint64_t mask, const char* mask_name, int blocks_per_cu = 1) {
   const int iters = 2000, blocks = 256 * blocks_per_cu, threads = 256 * wps;
-  uint64_t h = 0;
+  uint64_t h = 0, hv[2] = {0, 0};
   hipEvent_t e0, e1;
   CHK(hipEventCreate(&e0));
   CHK(hipEventCreate(&e1));
@@ -88,12 +95,15 @@ static void run_kind(uint64_t* d_out, int wps, uint64_t mask, const char* mask_n
   CHK(hipDeviceSynchronize());
   float ms = 0;
   CHK(hipEventElapsedTime(&ms, e0, e1));
-  CHK(hipMemcpy(&h, d_out, 8, hipMemcpyDeviceToHost));
+  CHK(hipMemcpy(hv, d_out, 16, hipMemcpyDeviceToHost));
+  h = hv[0];
+  const double ghz = hv[1] ? (double)hv[0] / (double)hv[1] * 0.1 : 0.0;  // shader clock during the probe
   const double n = (double)iters * 64.0;
   // wave-instructions per SIMD per nanosecond, from the wall clock of the launch
   const double rate = n * wps * blocks_per_cu / (ms * 1e6);
-  printf("%-20s waves/SIMD=%-2d lanes=%-12s memtime ticks/instr/wave=%7.2f  launch %.3f ms -> %.3f wave-instr/ns/SIMD\n", names[K],
-         wps * blocks_per_cu, mask_name, (double)h / n, ms, rate);
+  printf("%-20s waves/SIMD=%-2d lanes=%-12s memtime ticks/instr/wave=%7.2f  launch %.3f ms -> %.3f wave-instr/ns/SIMD"
+         "  clock %.2f GHz -> %.2f cycles/instr/SIMD\n", names[K],
+         wps * blocks_per_cu, mask_name, (double)h / n, ms, rate, ghz, ghz / rate);
   fflush(stdout);
   CHK(hipEventDestroy(e0));
   CHK(hipEventDestroy(e1));
@@ -133,6 +143,16 @@ int main(int argc, char** argv) {
       run_kind<K_SUB>(d_out, 4, ~0ull, "64", 2); run_kind<K_ADD>(d_out, 4, ~0ull, "64", 2); run_kind<K_LSHLADD>(d_out, 4, ~0ull, "64", 2);
       run_kind<K_MED3>(d_out, 4, ~0ull, "64", 2); run_kind<K_MIN3>(d_out, 4, ~0ull, "64", 2); run_kind<K_FMA>(d_out, 4, ~0ull, "64", 2);
       run_kind<K_MUL>(d_out, 4, ~0ull, "64", 2); run_kind<K_PKADD>(d_out, 4, ~0ull, "64", 2); run_kind<K_SALU>(d_out, 4, ~0ull, "64", 2);
+    }
+    return 0;
+  }
+  if (argc > 1 && argv[1][0] == 'f') {  // the forms of the fp32 multiply-add at 1, 2, 4, 8 waves per SIMD
+    for (int w = 1; w <= 8; w *= 2) {
+      const int wps = w > 4 ? 4 : w, bpc = w > 4 ? 2 : 1;
+      run_kind<K_ADD>(d_out, wps, ~0ull, "64", bpc); run_kind<K_FMAC>(d_out, wps, ~0ull, "64", bpc);
+      run_kind<K_FMA_ACC>(d_out, wps, ~0ull, "64", bpc); run_kind<K_FMA_ABC>(d_out, wps, ~0ull, "64", bpc);
+      run_kind<K_FMA>(d_out, wps, ~0ull, "64", bpc); run_kind<K_MAX>(d_out, wps, ~0ull, "64", bpc);
+      run_kind<K_CNDMASK>(d_out, wps, ~0ull, "64", bpc);
     }
     return 0;
   }

@@ -16,4 +16,8 @@ timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format c
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4_$TAG -- $B --steps 1 --warmup 0 --spp 256 > $OUT/pmc4_$TAG.log 2>&1 || exit 5
 timeout -s KILL 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/pmc5_$TAG -- $B --steps 1 --warmup 0 --spp 256 > $OUT/pmc5_$TAG.log 2>&1 || exit 6
 timeout -s KILL 120 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum --output-format csv -d $OUT/pmc6_$TAG -- $B --steps 1 --warmup 0 --spp 256 > $OUT/pmc6_$TAG.log 2>&1 || exit 7
+timeout -s KILL 120 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC SQ_INSTS_VALU SQ_INSTS_BRANCH --output-format csv -d $OUT/pmc7_$TAG -- $B --steps 1 --warmup 0 --spp 256 > $OUT/pmc7_$TAG.log 2>&1 || exit 8
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU SQ_INSTS_LDS_LOAD --output-format csv -d $OUT/pmc8_$TAG -- $B --steps 1 --warmup 0 --spp 256 > $OUT/pmc8_$TAG.log 2>&1 || exit 9
+# the kernel source these counters belong to: bench.py reports roofline.traffic only while it matches
+sha256sum $R/raytracing_amd/csrc/kernels.hip | cut -c1-16 > $OUT/kernels_hip_sha16_$TAG.txt
 echo done
