@@ -108,7 +108,7 @@ def main():
 
     from raytracing_amd import _abi as A
     from raytracing_amd import lib as ht
-    from raytracing_amd.distributed import shard_samples
+    from raytracing_amd.distributed import make_frame_step, shard_samples, timed_steps
     from raytracing_amd.scene import flatten, load_scene
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,35 +152,19 @@ def main():
 
     kernel_s = []
 
-    def step(timed):
-        accum.zero_()
-        if count > 0:
-            st = scene.render_accumulate(cam, params, accum.data_ptr(), stream, want_stats=timed)
-            if timed:
-                kernel_s.append((st["seconds_kernel"], st["launches"]))
-        if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
-        if rank == 0:
-            scene.resolve_device(accum.data_ptr(), W, H, spp, rgb_mean.data_ptr(), packed.data_ptr(), stream)
+    def render_shard(first_, count_, timed):
+        st = scene.render_accumulate(cam, params, accum.data_ptr(), stream, want_stats=timed)
+        if timed:
+            kernel_s.append((st["seconds_kernel"], st["launches"]))
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def resolve_on_root():
+        scene.resolve_device(accum.data_ptr(), W, H, spp, rgb_mean.data_ptr(), packed.data_ptr(), stream)
 
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # the frame loop and its timing are host logic shared with the CPU (gloo) test of the
+    # multi-rank path: raytracing_amd/distributed.py
+    step = make_frame_step(spp, rank, world, accum, render_shard, resolve_on_root, dist)
+    elapsed = timed_steps(step, args.steps, args.warmup, world, dist, torch.cuda.synchronize,
+                          lambda x: torch.tensor([x], dtype=torch.float64, device=dev))
 
     if rank == 0:
         total_samples = W * H * spp
@@ -197,16 +181,27 @@ def main():
         achieved = flops_per_sample * rank_samples / max(ksec, 1e-9) / 1e12
         info = scene.info()
         # HBM bytes per launch as the PMC passes of the committed profile measured them
-        # (counters cannot be read from inside this process); scaled to this run's launch size
-        traffic = None
+        # (counters cannot be read from inside this process), scaled to this run's launch
+        # size; only while the profile was taken on the kernel source that runs here
+        traffic, traffic_note = None, None
         try:
+            import hashlib
+            with open(os.path.join(ROOT, "raytracing_amd", "csrc", "kernels.hip"), "rb") as f:
+                sha16 = hashlib.sha256(f.read()).hexdigest()[:16]
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 tr = json.load(f).get(args.workload)
-            if tr and launches:
+            if not tr:
+                traffic_note = "no PMC profile of this workload under profiles/"
+            elif tr.get("kernels_hip_sha16") != sha16:
+                traffic_note = ("profiles/traffic.json was measured on another version of kernels.hip "
+                                f"({tr.get('kernels_hip_sha16')} != {sha16}): run tools/prof.sh and tools/update_traffic.py")
+            elif launches:
                 spp_per_launch = count * args.steps / launches
                 traffic = (tr["fetch_bytes"] + tr["write_bytes"]) * spp_per_launch / tr["spp_per_launch"]
-        except (OSError, ValueError, KeyError):
-            traffic = None
+                traffic_note = ("HBM-side bytes per launch (FETCH_SIZE + WRITE_SIZE PMC passes, %s); almost all of it "
+                                "is the 64-bit atomic adds that flush tile sums to the frame" % tr["source"])
+        except (OSError, ValueError, KeyError) as e:
+            traffic, traffic_note = None, f"traffic record unreadable: {e}"
         out = {
             "metric": "Msamples/s (camera paths per second), dragon.json 1920x1080 1024 spp"
             if args.workload == "dragon" else f"Msamples/s (camera paths per second), {args.workload}",
@@ -235,8 +230,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / FP32_VALU_PEAK_TFLOPS,
                 "traffic": traffic,
-                "traffic_note": "HBM bytes per launch (FETCH_SIZE + WRITE_SIZE PMC passes, profiles/traffic.json); "
-                                "almost all of it is the 64-bit atomic adds that flush tile sums to the frame",
+                "traffic_note": traffic_note,
                 "kernel": "render_kernel<float,false>",
                 "flops_per_sample": flops_per_sample,
                 "kernel_ms_per_launch": ksec / max(launches, 1) * 1e3,

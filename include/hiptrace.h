@@ -330,6 +330,7 @@ int ht_scene_get_info(const ht_scene* scene, ht_scene_info* out);
  *                       waiting lanes / travelling lanes >= num / den
  *   "default_batch"     samples per launch when ht_render_params.batch = 0
  *   "chunk"             samples of one 8x8 tile that form one unit of the work queue
+ *                       (0, the default: 16 for launches of 1024 samples or more, else 8)
  *   "chunk_tail"        the same for the last "chunk" samples of a launch (smaller units
  *                       at the end shorten the tail of the launch)
  *   "force_hbm_scene"   scenes created while this is 1 keep their image in HBM even if it

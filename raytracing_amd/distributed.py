@@ -35,3 +35,54 @@ def render_sharded(accumulate: Callable[[int, int], "object"], samples: int, ran
     if world > 1:
         reduce_sum_to_root(buf)
     return buf
+
+
+def make_frame_step(samples: int, rank: int, world: int, accum, render_shard: Callable[[int, int, bool], None],
+                    resolve_on_root: Callable[[], None], dist=None) -> Callable[[bool], None]:
+    """One frame as the benchmark and a multi-process host run it: zero this rank's sum
+    buffer, `render_shard(first, count, timed)` adds the rank's sample range into it,
+    `dist.reduce(SUM)` brings the sums to rank 0, and rank 0 resolves the picture.
+
+    `accum` is a tensor of int64 sums (32.32 fixed point) on whatever device the backend of
+    `dist` reduces on; `dist` is torch.distributed (None or world 1: no reduce)."""
+    first, count = shard_samples(samples, rank, world)
+
+    def step(timed: bool) -> None:
+        accum.zero_()
+        if count > 0:
+            render_shard(first, count, timed)
+        if world > 1:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            resolve_on_root()
+
+    return step
+
+
+def timed_steps(step: Callable[[bool], None], steps: int, warmup: int, world: int, dist=None,
+                device_sync: Callable[[], None] = lambda: None, max_tensor: Callable[[float], "object"] = None) -> float:
+    """`warmup` untimed steps, then exactly `steps` timed ones bracketed by device sync +
+    barrier + device sync on both sides; returns the elapsed seconds of the slowest rank
+    (all_reduce MAX), the same number on every rank.  `max_tensor(x)` makes the one-element
+    float64 tensor the backend can reduce (a device tensor for RCCL)."""
+    import time
+
+    def fence():
+        device_sync()
+        if world > 1:
+            dist.barrier()
+        device_sync()
+
+    for _ in range(warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = max_tensor(elapsed)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed

@@ -68,3 +68,63 @@ def test_two_rank_gloo_frame_equals_single_rank(tmp_path, oracle_mod, flat_scene
     cam, _, flat = flat_scene("scene")
     whole = oracle_mod.OracleScene(flat).render(cam, 32, 18, 5, seed=11, nthreads=1)["rgb"]
     np.testing.assert_allclose(got, whole, rtol=1e-13, atol=1e-13)
+
+
+def _bench_loop_worker(rank, world, port, out_path):
+    """bench.py's own frame loop (make_frame_step + timed_steps) with CPU tensors over gloo.
+    The renderer is a stand-in that adds a known integer per (pixel, global sample index),
+    so the reduced frame has a closed form and any lost, doubled or misplaced sample shows."""
+    sys.path.insert(0, ROOT)
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    from raytracing_amd.distributed import make_frame_step, timed_steps
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_pix, spp = 96, 11
+    accum = torch.zeros(n_pix * 3, dtype=torch.int64)
+    frames, calls = [], []
+    pix = torch.arange(n_pix * 3, dtype=torch.int64)
+
+    def render_shard(first, count, timed):
+        calls.append((first, count, timed))
+        for s_ in range(first, first + count):
+            accum.add_(pix * 1000 + s_ * s_ + 1)
+        if rank == 1:
+            time.sleep(0.03)  # a slow rank: the reported time must be the maximum over ranks
+
+    def resolve_on_root():
+        frames.append(accum.clone())
+
+    step = make_frame_step(spp, rank, world, accum, render_shard, resolve_on_root, dist)
+    elapsed = timed_steps(step, 3, 1, world, dist, lambda: None, lambda x: torch.tensor([x], dtype=torch.float64))
+    torch.save({"elapsed": elapsed, "frames": frames, "calls": calls}, f"{out_path}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_frame_loop_two_ranks_gloo(tmp_path):
+    import torch
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "loop")
+    mp.spawn(_bench_loop_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    n_pix, spp = 96, 11
+    pix = torch.arange(n_pix * 3, dtype=torch.int64)
+    whole = sum(pix * 1000 + s_ * s_ + 1 for s_ in range(spp))
+    # rank 0 resolved once per step (1 warm-up + 3 timed), each time the complete frame
+    assert len(r0["frames"]) == 4 and all(torch.equal(f, whole) for f in r0["frames"])
+    assert r1["frames"] == []
+    # contiguous sample ranges, the warm-up step untimed
+    assert r0["calls"] == [(0, 6, False)] + [(0, 6, True)] * 3
+    assert r1["calls"] == [(6, 5, False)] + [(6, 5, True)] * 3
+    # one elapsed time for the job: the slow rank's, on both ranks
+    assert r0["elapsed"] == r1["elapsed"] >= 3 * 0.03

@@ -257,7 +257,7 @@ def test_full_size_properties(dev, flat_scene, name, W, H):
     try:
         assert np.array_equal(whole, sums(0, 6).to_host())
     finally:
-        dev.set_option("chunk", 8)
+        dev.set_option("chunk", 0)
     # radiance is bounded by the brightest source times the largest albedo chain (<= 1)
     one = 2.0 ** 32
     bright = 15.0 if name == "cornell" else 1.0
