@@ -56,7 +56,7 @@ def test_options_need_no_device(ht):
         rc = ht.load().ht_set_option(name.encode(), 0 if name in ("block_threads", "force_hbm_scene") else 8)
         assert rc == 0, name
     # back to the defaults the library starts with
-    for name, v in (("wait_threshold", 40), ("max_blocks_per_cu", 8), ("default_batch", 1024), ("chunk", 8), ("chunk_tail", 4),
+    for name, v in (("wait_threshold", 40), ("max_blocks_per_cu", 8), ("default_batch", 1024), ("chunk", 0), ("chunk_tail", 4),
                     ("block_threads", 0), ("node_den", 2), ("wait_ratio_num", 1000), ("wait_ratio_den", 1)):
         ht.set_option(name, v)
     with pytest.raises(ht.HipTraceError) as e:
