@@ -15,6 +15,10 @@
 
 namespace rt {
 
+// A texture file is untrusted input: sizes are capped before anything is allocated from them.
+static const uint32_t kMaxImageSide = 65535;
+static const uint64_t kMaxImagePixels = 1ull << 28;
+
 // =============================== PNG ============================================
 static uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
 
@@ -54,6 +58,8 @@ Image decodePNG(const std::vector<uint8_t>& bytes) {
     pos += 12 + (size_t)len;
   }
   if (ctype < 0 || width == 0 || height == 0) throw std::runtime_error("PNG: no IHDR");
+  if (width > kMaxImageSide || height > kMaxImageSide || (uint64_t)width * height > kMaxImagePixels)
+    throw std::runtime_error("PNG: picture too large");
   if (interlace) throw std::runtime_error("PNG: interlaced files are not supported");
   int channels;
   switch (ctype) {
@@ -223,12 +229,16 @@ const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18,
                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
 void build_huff(Huff& h, const uint8_t* bits /*[1..16]*/, const uint8_t* vals, int nvals) {
+  if (nvals < 0 || nvals > 256) throw std::runtime_error("JPEG: bad DHT");
   std::memcpy(h.vals, vals, (size_t)nvals);
   int code = 0, k = 0;
   std::memset(h.look_len, 0, sizeof h.look_len);
   for (int len = 1; len <= 16; ++len) {
     h.valptr[len] = k;
     h.mincode[len] = code;
+    // the code lengths must form a prefix code: no more codes of a length than that length has left
+    if (code + (int)bits[len] > (1 << len) || k + (int)bits[len] > nvals)
+      throw std::runtime_error("JPEG: DHT code lengths are not a prefix code");
     for (int i = 0; i < bits[len]; ++i, ++k, ++code) {
       if (len <= 9) {
         int first = code << (9 - len);
@@ -280,7 +290,7 @@ void idct_islow(const int* coef /*dequantised, natural order*/, uint8_t* out, in
     long z1 = (z2 + z3) * F0_541;
     long t2 = z1 + z3 * (-F1_847), t3 = z1 + z2 * F0_765;
     z2 = in[0]; z3 = in[32];
-    long t0 = (z2 + z3) << CB, t1 = (z2 - z3) << CB;
+    long t0 = (z2 + z3) * (1L << CB), t1 = (z2 - z3) * (1L << CB);
     long t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
     t0 = in[56]; t1 = in[40]; t2 = in[24]; t3 = in[8];
     z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2;
@@ -300,7 +310,7 @@ void idct_islow(const int* coef /*dequantised, natural order*/, uint8_t* out, in
     long z2 = w[2], z3 = w[6];
     long z1 = (z2 + z3) * F0_541;
     long t2 = z1 + z3 * (-F1_847), t3 = z1 + z2 * F0_765;
-    long t0 = (w[0] + w[4]) << CB, t1 = (w[0] - w[4]) << CB;
+    long t0 = (w[0] + w[4]) * (1L << CB), t1 = (w[0] - w[4]) * (1L << CB);
     long t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
     t0 = w[7]; t1 = w[5]; t2 = w[3]; t3 = w[1];
     z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2;
@@ -449,6 +459,12 @@ Image decodeJPEG(const std::vector<uint8_t>& bytes) {
           hmax = std::max(hmax, comps[i].h);
           vmax = std::max(vmax, comps[i].v);
         }
+        // every component must divide the largest sampling factors (the upsampler replicates or
+        // filters by whole ratios), and the picture must be of a size worth allocating
+        for (int i = 0; i < n; ++i)
+          if (hmax % comps[i].h != 0 || vmax % comps[i].v != 0)
+            throw std::runtime_error("JPEG: fractional sampling ratios are not supported");
+        if ((uint64_t)W * (uint64_t)H > kMaxImagePixels) throw std::runtime_error("JPEG: picture too large");
         break;
       }
       case 0xC2: case 0xC3: case 0xC5: case 0xC6: case 0xC7: case 0xC9: case 0xCA: case 0xCB: case 0xCD: case 0xCE: case 0xCF:
@@ -461,8 +477,10 @@ Image decodeJPEG(const std::vector<uint8_t>& bytes) {
         break;
       case 0xDA: {  // SOS: one interleaved scan of all components
         if (comps.empty()) throw std::runtime_error("JPEG: SOS before SOF");
+        if (len < 3) throw std::runtime_error("JPEG: bad SOS");
         int ns = seg[0];
         if (ns != (int)comps.size()) throw std::runtime_error("JPEG: non-interleaved scans are not supported");
+        if (len < 2 + 1 + 2 * ns + 3) throw std::runtime_error("JPEG: bad SOS");
         for (int i = 0; i < ns; ++i) {
           int cid = seg[1 + 2 * i];
           Component* c = nullptr;
