@@ -99,6 +99,10 @@ def main():
     ap.add_argument("--workload", default="dragon", choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
     ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="frames in flight, each with its own buffers and HIP stream.  2 lets the drain of one frame "
+                         "overlap the start of the next, but two resident persistent launches share the CUs badly: "
+                         "measured 103.2 instead of 94.9 ms per dragon frame on one GPU, so 1 is the default")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the CPU baseline and the host-buffer leg (profiling runs)")
     args = ap.parse_args()
@@ -108,7 +112,7 @@ def main():
 
     from raytracing_amd import _abi as A
     from raytracing_amd import lib as ht
-    from raytracing_amd.distributed import make_frame_step, shard_samples, timed_steps
+    from raytracing_amd.distributed import FrameSlot, make_frame_step, shard_samples, timed_steps
     from raytracing_amd.scene import flatten, load_scene
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,28 +147,58 @@ def main():
     scene = ht.Scene(flat, device=local_rank)
     first, count = shard_samples(spp, rank, world)
 
-    accum = torch.zeros(H * W * 3, dtype=torch.int64, device=dev)  # 32.32 fixed-point radiance sums
-    rgb_mean = torch.empty(H * W * 3, dtype=torch.float32, device=dev)
-    packed = torch.empty(H * W, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
     params = ht.make_params(W, H, max(count, 1), sample_offset=first, seed=2025, batch=args.batch,
                             device=local_rank)
+    launch_events = []  # (start, stop) around every render call of the timed region, on its stream
 
-    kernel_s = []
+    def frame_slot():
+        """Buffers and stream of one frame in flight: 32.32 fixed-point radiance sums, the
+        two pictures, and a HIP stream of its own."""
+        accum = torch.zeros(H * W * 3, dtype=torch.int64, device=dev)
+        rgb_mean = torch.empty(H * W * 3, dtype=torch.float32, device=dev)
+        packed = torch.empty(H * W, dtype=torch.int32, device=dev)
+        tstream = torch.cuda.Stream(device=dev)
 
-    def render_shard(first_, count_, timed):
-        st = scene.render_accumulate(cam, params, accum.data_ptr(), stream, want_stats=timed)
-        if timed:
-            kernel_s.append((st["seconds_kernel"], st["launches"]))
+        def render_shard(first_, count_, timed):
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(tstream)
+            # enqueue only: nothing here waits for the device, so frames overlap
+            scene.render_accumulate(cam, params, accum.data_ptr(), tstream.cuda_stream, want_stats=False)
+            if timed:
+                e1.record(tstream)
+                launch_events.append((e0, e1))
 
-    def resolve_on_root():
-        scene.resolve_device(accum.data_ptr(), W, H, spp, rgb_mean.data_ptr(), packed.data_ptr(), stream)
+        def resolve():
+            scene.resolve_device(accum.data_ptr(), W, H, spp, rgb_mean.data_ptr(), packed.data_ptr(),
+                                 tstream.cuda_stream)
+
+        return FrameSlot(accum, render_shard, resolve, lambda: torch.cuda.stream(tstream))
 
     # the frame loop and its timing are host logic shared with the CPU (gloo) test of the
     # multi-rank path: raytracing_amd/distributed.py
-    step = make_frame_step(spp, rank, world, accum, render_shard, resolve_on_root, dist)
+    in_flight = max(1, args.frames_in_flight)
+    slots = [frame_slot() for _ in range(in_flight)]
+    step = make_frame_step(spp, rank, world, slots, dist)
     elapsed = timed_steps(step, args.steps, args.warmup, world, dist, torch.cuda.synchronize,
                           lambda x: torch.tensor([x], dtype=torch.float64, device=dev))
+    launches_per_call = -(-max(count, 1) // (args.batch if args.batch > 0 else 1024))
+    accum = slots[0].accum
+    stream = torch.cuda.current_stream().cuda_stream
+    if in_flight == 1:
+        # HIP events on the stream the kernel ran on, around every render call of the timed region
+        kernel_s = [(e0.elapsed_time(e1) * 1e-3, launches_per_call) for e0, e1 in launch_events]
+        kernel_timing = "HIP events around every launch of the timed region"
+    else:
+        # overlapping frames share the GPU, so a launch's own duration is not defined inside the
+        # timed region: time this rank's launch alone, once more, after it
+        accum.zero_()
+        if count > 0:
+            st = scene.render_accumulate(cam, params, accum.data_ptr(), stream, want_stats=True)
+            kernel_s = [(st["seconds_kernel"], st["launches"])] * max(args.steps, 1)
+        else:
+            kernel_s = []
+        kernel_timing = "HIP events around one launch run alone after the timed region (frames overlap inside it)"
 
     if rank == 0:
         total_samples = W * H * spp
@@ -220,6 +254,7 @@ def main():
             else "synthetic: the reference's own scene file (scenes/%s) rendered with a fixed Philox seed" % fname,
             "config": {"workload": f"{fname} {W}x{H} {spp} spp, max depth 50", "width": W, "height": H,
                        "spp": spp, "parallelism": f"spp sharded over {world} GPU(s), reduce(sum) to rank 0",
+                       "frames_in_flight": in_flight,
                        "prims": info["n_prims"], "bvh_nodes": info["n_nodes"],
                        "scene_image_bytes": info["lds_bytes_fp32"],
                        "scene_store": "hbm" if info["hbm_store_fp32"] else "lds"},
@@ -234,6 +269,7 @@ def main():
                 "kernel": "render_kernel<float,false>",
                 "flops_per_sample": flops_per_sample,
                 "kernel_ms_per_launch": ksec / max(launches, 1) * 1e3,
+                "kernel_timing": kernel_timing,
                 "launches_per_step": launches / max(args.steps, 1),
                 "counters_per_sample": {k: (ctr[k] / ctr["samples"]) for k in
                                         ("n_rays", "n_box", "n_sphere", "n_rect", "n_tri")},

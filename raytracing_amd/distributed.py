@@ -9,7 +9,7 @@ on the GLOBAL sample index, the set of paths is the same for every rank count.
 """
 from __future__ import annotations
 
-from typing import Callable, Tuple
+from typing import Callable, List, Tuple
 
 
 def shard_samples(samples: int, rank: int, world: int) -> Tuple[int, int]:
@@ -37,24 +37,42 @@ def render_sharded(accumulate: Callable[[int, int], "object"], samples: int, ran
     return buf
 
 
-def make_frame_step(samples: int, rank: int, world: int, accum, render_shard: Callable[[int, int, bool], None],
-                    resolve_on_root: Callable[[], None], dist=None) -> Callable[[bool], None]:
-    """One frame as the benchmark and a multi-process host run it: zero this rank's sum
-    buffer, `render_shard(first, count, timed)` adds the rank's sample range into it,
-    `dist.reduce(SUM)` brings the sums to rank 0, and rank 0 resolves the picture.
+class FrameSlot:
+    """The buffers of one frame in flight.  `accum` is the tensor of int64 radiance sums
+    (32.32 fixed point) on whatever device the backend of `dist` reduces on;
+    `render_shard(first, count, timed)` adds this rank's sample range into it; `resolve()`
+    turns the reduced sums into the picture (rank 0 only); `stream()` returns a context
+    manager that makes the slot's stream current (a HIP stream per slot lets the tail of one
+    frame overlap the start of the next; the default does nothing)."""
 
-    `accum` is a tensor of int64 sums (32.32 fixed point) on whatever device the backend of
-    `dist` reduces on; `dist` is torch.distributed (None or world 1: no reduce)."""
+    def __init__(self, accum, render_shard: Callable[[int, int, bool], None], resolve: Callable[[], None],
+                 stream: Callable[[], "object"] = None):
+        import contextlib
+
+        self.accum, self.render_shard, self.resolve = accum, render_shard, resolve
+        self.stream = stream or contextlib.nullcontext
+
+
+def make_frame_step(samples: int, rank: int, world: int, slots: List[FrameSlot], dist=None) -> Callable[[bool], None]:
+    """One frame as the benchmark and a multi-process host run it: zero this rank's sum
+    buffer, add the rank's sample range into it, `dist.reduce(SUM)` to rank 0, and rank 0
+    resolves the picture.  Successive frames take the slots in turn: with two slots on two
+    streams the drain of frame k (its last long paths, its reduce and resolve) overlaps the
+    render of frame k + 1.  `dist` is torch.distributed (None or world 1: no reduce)."""
     first, count = shard_samples(samples, rank, world)
+    frame_no = [0]
 
     def step(timed: bool) -> None:
-        accum.zero_()
-        if count > 0:
-            render_shard(first, count, timed)
-        if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
-        if rank == 0:
-            resolve_on_root()
+        slot = slots[frame_no[0] % len(slots)]
+        frame_no[0] += 1
+        with slot.stream():
+            slot.accum.zero_()
+            if count > 0:
+                slot.render_shard(first, count, timed)
+            if world > 1:
+                dist.reduce(slot.accum, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                slot.resolve()
 
     return step
 

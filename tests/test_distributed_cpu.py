@@ -80,27 +80,28 @@ def _bench_loop_worker(rank, world, port, out_path):
     import torch
     import torch.distributed as dist
 
-    from raytracing_amd.distributed import make_frame_step, timed_steps
+    from raytracing_amd.distributed import FrameSlot, make_frame_step, timed_steps
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n_pix, spp = 96, 11
-    accum = torch.zeros(n_pix * 3, dtype=torch.int64)
     frames, calls = [], []
     pix = torch.arange(n_pix * 3, dtype=torch.int64)
 
-    def render_shard(first, count, timed):
-        calls.append((first, count, timed))
-        for s_ in range(first, first + count):
-            accum.add_(pix * 1000 + s_ * s_ + 1)
-        if rank == 1:
-            time.sleep(0.03)  # a slow rank: the reported time must be the maximum over ranks
+    def slot():  # two frames in flight, as bench.py runs them
+        accum = torch.zeros(n_pix * 3, dtype=torch.int64)
 
-    def resolve_on_root():
-        frames.append(accum.clone())
+        def render_shard(first, count, timed):
+            calls.append((first, count, timed))
+            for s_ in range(first, first + count):
+                accum.add_(pix * 1000 + s_ * s_ + 1)
+            if rank == 1:
+                time.sleep(0.03)  # a slow rank: the reported time must be the maximum over ranks
 
-    step = make_frame_step(spp, rank, world, accum, render_shard, resolve_on_root, dist)
+        return FrameSlot(accum, render_shard, lambda: frames.append(accum.clone()))
+
+    step = make_frame_step(spp, rank, world, [slot(), slot()], dist)
     elapsed = timed_steps(step, 3, 1, world, dist, lambda: None, lambda x: torch.tensor([x], dtype=torch.float64))
     torch.save({"elapsed": elapsed, "frames": frames, "calls": calls}, f"{out_path}.{rank}")
     dist.barrier()
