@@ -48,6 +48,9 @@ struct ht_scene {
   uint32_t feat = 0;  // KFEAT_* texture kinds present in the scene
   std::mutex shape_mutex;
   LaunchShape shape[2][2];  // [precision][counters]
+  // workspace of the wavefront variant (path state between the stage kernels), grown on demand
+  uint8_t* d_wf = nullptr;
+  size_t wf_bytes = 0;
 };
 
 struct ht_frame {
@@ -105,6 +108,9 @@ std::atomic<int> g_default_batch{1024};
 std::atomic<int> g_chunk{0};  // 0: by launch size
 std::atomic<int> g_chunk_tail{4};
 std::atomic<int> g_force_hbm{0};     // scenes created while set keep their image in HBM
+std::atomic<int> g_wavefront{0};      // 1: fp32 renders run the wavefront variant
+std::atomic<int> g_wavefront_cap{1 << 24};
+std::atomic<int> g_wavefront_refill{32};  // paths in flight of the wavefront variant
 std::atomic<int> g_shape_generation{0};  // bumped by the options a launch shape depends on
 
 // Makes `device` current for the lifetime of the object, then restores.
@@ -276,6 +282,92 @@ hipError_t enqueue_launch(const RenderPlan& pl, uint32_t* queue_head, int first,
   return e;
 }
 
+
+// The wavefront variant of one launch: samples [first, first + count) of every pixel, added to
+// the plan's sum buffer.  Stage kernels over path state in global memory; the number of paths
+// that survive a shade stage is read back each round, so the call synchronises with `stream`.
+int render_wavefront(ht_scene* s, const RenderPlan& pl, int first, int count, hipStream_t stream) {
+  const RenderArgs& ra = pl.a;
+  const uint64_t WH = (uint64_t)ra.W * (uint64_t)ra.H;
+  // a sub-launch holds at most 2^28 items: their contributions (12 bytes each, 3.2 GB at most)
+  // are kept until the reduce, and every sub-launch pays the drain of its last long paths
+  // (tens of rounds with few rays) once
+  const int max_count = (int)std::max<uint64_t>(1, ((uint64_t)1 << 28) / WH);
+  for (int done = 0; done < count; done += max_count) {
+    const int n_s = std::min(max_count, count - done);
+    const uint64_t items = WH * (uint64_t)n_s;
+    if (items > 0xFFFFFFF0ull) return fail(HT_E_TOO_LARGE, "picture too large for the wavefront variant");
+    const uint64_t cap = std::min<uint64_t>((uint64_t)g_wavefront_cap.load(), (items + 255) & ~(uint64_t)255);
+    // [ray 6][thr 3][ids 2] x 2 buffers, hit_t, hit_ref: 24 words per path; contributions: 3 per item
+    const size_t bytes = (size_t)cap * 24 * 4 + (size_t)items * 3 * 4 + 256;
+    if (bytes > s->wf_bytes) {
+      if (s->d_wf) (void)hipFree(s->d_wf);
+      s->d_wf = nullptr;
+      s->wf_bytes = 0;
+      HIP_TRY(hipMalloc((void**)&s->d_wf, bytes));
+      s->wf_bytes = bytes;
+    }
+    WfArgs a;
+    memset(&a, 0, sizeof a);
+    a.blob = ra.blob;
+    a.L = ra.L;
+    a.texels = ra.texels;
+    a.accum = ra.accum;
+    a.cap = (uint32_t)cap;
+    a.items = (uint32_t)items;
+    a.WH = (uint32_t)WH;
+    a.W = ra.W;
+    a.H = ra.H;
+    a.sample_first = first + done;
+    a.max_depth = ra.max_depth;
+    a.jitter = ra.jitter;
+    a.refill = g_wavefront_refill.load();
+    memcpy(a.philox_keys, ra.philox_keys, sizeof a.philox_keys);
+    float* w = (float*)s->d_wf;
+    WfBuffers b0, b1;
+    b0.ray = w; w += 6 * cap;
+    b0.thr = w; w += 3 * cap;
+    b0.ids = (uint32_t*)w; w += 2 * cap;
+    b1.ray = w; w += 6 * cap;
+    b1.thr = w; w += 3 * cap;
+    b1.ids = (uint32_t*)w; w += 2 * cap;
+    a.hit_t = w; w += cap;
+    a.hit_ref = (uint32_t*)w; w += cap;
+    a.contrib = w; w += 3 * items;
+    a.counters = (uint32_t*)w;
+    a.cur = b0;
+    a.nxt = b1;
+    HIP_TRY(hipMemsetAsync(a.contrib, 0, (size_t)items * 3 * 4, stream));
+    uint64_t next = 0;
+    uint32_t live = 0;
+    for (int round = 0; live > 0 || next < items; ++round) {
+      if (round > 1000000) return fail(HT_E_HIP, "wavefront variant: no progress");
+      const uint32_t g = (uint32_t)std::min<uint64_t>(cap - live, items - next);
+      a.n_new = g;
+      a.slot0 = live;
+      a.item0 = (uint32_t)next;
+      HIP_TRY(launch_wf_generate(a, pl.cam32, stream));
+      live += g;
+      next += g;
+      a.n = live;
+      HIP_TRY(hipMemsetAsync(a.counters, 0, 256, stream));
+      // no more workgroups than the rays can feed (every wave starts with a block of 64 or more)
+      const int wg_rays = pl.shape.threads * 4;
+      const int trace_grid = (int)std::min<uint64_t>((uint64_t)pl.grid, ((uint64_t)live + wg_rays - 1) / wg_rays);
+      HIP_TRY(launch_wf_trace(pl.kfeat, a, std::max(1, trace_grid), pl.shape.threads, pl.shape.lds, stream));
+      HIP_TRY(launch_wf_shade(pl.kfeat, a, pl.cam32, stream));
+      uint32_t survivors = 0;
+      HIP_TRY(hipMemcpyAsync(&survivors, a.counters, 4, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      if (survivors > live) return fail(HT_E_HIP, "wavefront variant: compaction counter out of range");
+      live = survivors;
+      std::swap(a.cur, a.nxt);
+    }
+    HIP_TRY(launch_wf_reduce(a, (uint32_t)n_s, stream));
+  }
+  return HT_OK;
+}
+
 uint32_t* next_queue_head(ht_scene* s) {
   return (uint32_t*)(s->d_queue_heads + (size_t)(s->next_head.fetch_add(1) % QUEUE_SLOTS) * QUEUE_SLOT_BYTES);
 }
@@ -316,6 +408,7 @@ int render_accumulate_impl(ht_scene* s, const ht_camera* cam, const ht_render_pa
 
   int launches = 0, done = 0;
   bool cancelled = false;
+  const bool wavefront = g_wavefront.load() != 0 && pl.prec == HT_PRECISION_FP32 && !pl.counters;
   hipError_t e = hipEventRecord(ev_start, stream);
   while (e == hipSuccess && done < p->samples) {
     // keep at most two batches in flight so that a cancel request is seen soon
@@ -323,7 +416,12 @@ int render_accumulate_impl(ht_scene* s, const ht_camera* cam, const ht_render_pa
     if (e != hipSuccess) break;
     if (s->cancel.exchange(0)) { cancelled = true; break; }
     const int count = std::min(pl.batch, p->samples - done);
-    e = enqueue_launch(pl, next_queue_head(s), p->sample_offset + done, count, stream);
+    if (wavefront) {
+      const int wrc = render_wavefront(s, pl, p->sample_offset + done, count, stream);
+      if (wrc != HT_OK) { cleanup(); return wrc; }
+    } else {
+      e = enqueue_launch(pl, next_queue_head(s), p->sample_offset + done, count, stream);
+    }
     if (e == hipSuccess) e = hipEventRecord(ev_batch[launches & 1], stream);
     if (e == hipSuccess) {
       done += count;
@@ -414,6 +512,9 @@ int ht_set_option(const char* name, int value) {
   if (!strcmp(name, "wait_ratio_num")) { g_wait_num = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "wait_ratio_den")) { g_wait_den = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "force_hbm_scene")) { g_force_hbm = value ? 1 : 0; return HT_OK; }
+  if (!strcmp(name, "wavefront")) { g_wavefront = value ? 1 : 0; return HT_OK; }
+  if (!strcmp(name, "wavefront_refill")) { g_wavefront_refill = std::min(64, std::max(1, value)); return HT_OK; }
+  if (!strcmp(name, "wavefront_paths")) { g_wavefront_cap = std::min(1 << 26, std::max(1 << 12, value)); return HT_OK; }
   return fail(HT_E_INVALID, "unknown option '%s'", name);
 }
 
@@ -426,6 +527,7 @@ void ht_scene_destroy(ht_scene* s) {
     if (s->d_texels) (void)hipFree(s->d_texels);
     if (s->d_queue_heads) (void)hipFree(s->d_queue_heads);
     if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->d_wf) (void)hipFree(s->d_wf);
   }
   delete s;
 }

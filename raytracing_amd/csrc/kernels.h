@@ -40,6 +40,41 @@ struct RenderArgs {
   int32_t wait_ratio_num, wait_ratio_den;  // traversal also yields when waiting/travelling >= num/den
 };
 
+// ---- wavefront variant: the same paths as render_kernel, one kernel per stage ----------
+// Path state lives in global memory between the stages, structure-of-arrays with `cap`
+// elements per array:
+//   ray  [6][cap]  origin, direction            thr [3][cap]  throughput T
+//   ids  [2][cap]  item (pixel + sample * W*H within the launch), bounce
+//   hit_t [cap], hit_ref [cap]                  closest hit of the ray (hit_ref = empty: miss)
+//   contrib [3][items]                          what the path added to its pixel, stored once
+struct WfBuffers {
+  float* ray;
+  float* thr;
+  uint32_t* ids;
+};
+struct WfArgs {
+  const uint8_t* blob;
+  SceneLayout L;
+  const uint32_t* texels;
+  WfBuffers cur, nxt;
+  float* hit_t;
+  uint32_t* hit_ref;
+  float* contrib;
+  uint32_t* counters;     // [0]: paths written to nxt by the shade stage, [1]: next ray of the trace stage
+  long long* accum;
+  uint32_t cap;           // elements per array
+  uint32_t n;             // paths in cur
+  uint32_t n_new, slot0;  // generate: paths to start and where the first one goes in cur
+  uint32_t item0;         // generate: first item to start
+  uint32_t items;         // items of the launch = W*H * samples
+  uint32_t WH;
+  int32_t W, H;
+  int32_t sample_first;   // global index of the launch's first sample
+  int32_t max_depth, jitter;
+  int32_t refill;         // trace: idle lanes of a wave that trigger a refill from the ray list
+  uint32_t philox_keys[20];
+};
+
 struct FirstHitArgs {
   const uint8_t* blob;
   SceneLayout L;
@@ -84,6 +119,13 @@ hipError_t launch_first_hit(int precision, const FirstHitArgs& a, const void* ca
 hipError_t launch_accum_add(long long* dst, const long long* src, size_t n, hipStream_t stream);
 // dst[i] += sum over j < count of src[j * n + i]: the other shards' copies of one slice of the frame
 hipError_t launch_accum_add_many(long long* dst, const long long* src, size_t n, int count, hipStream_t stream);
+
+// wavefront stages (fp32 arithmetic).  `feat` as for launch_render; the store is a.L.wide.
+hipError_t launch_wf_generate(const WfArgs& a, const CamDev<float>& cam, hipStream_t stream);
+hipError_t launch_wf_trace(uint32_t feat, const WfArgs& a, int grid_blocks, int threads, uint32_t lds_bytes,
+                           hipStream_t stream);
+hipError_t launch_wf_shade(uint32_t feat, const WfArgs& a, const CamDev<float>& cam, hipStream_t stream);
+hipError_t launch_wf_reduce(const WfArgs& a, uint32_t samples, hipStream_t stream);
 
 // The library's static device array (see kernels.hip): the address of the current device's
 // copy, looked up once per device.  Layout: radiance sums of HT_NOALLOC_MAX_PIXELS pixels

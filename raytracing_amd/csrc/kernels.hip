@@ -740,8 +740,13 @@ __device__ __forceinline__ V3<R> unit_vector_from(R u0, R u1) {
 // Radiance sums are kept in signed 32.32 fixed point: integer adds commute, so a
 // pixel's sum does not depend on the order in which its paths finish, on how
 // the frame is cut into launches or on how many GPUs share it.
+// (No fused multiply-add across this function: inlined behind `T * e`, a contraction of
+// x - floor(x) with the product would convert the unrounded product, and the sum would then
+// depend on whether the caller held x in a register or had stored it as a number first.)
 template <typename R>
 __device__ __forceinline__ long long to_fixed(R x) {
+#pragma clang fp contract(off)
+  asm volatile("" : "+v"(x));  // x is a rounded number of type R from here on
   const R f = M<R>::floor(x);
   const int hi = (int)f;                                        // saturates; NaN -> 0
   const unsigned lo = (unsigned)((x - f) * (R)4294967296.0);    // [0, 2^32)
@@ -771,6 +776,20 @@ __device__ __forceinline__ void deposit(const Sink& k, V3<R> c) {
   }
 }
 
+// The wavefront kernels' sink: a path contributes once, when it ends, so its contribution
+// is stored (not added) at the path's own place in a buffer that a later kernel sums per
+// pixel; no atomics.
+struct StoreSink {
+  float* c;         // this path's red value; green and blue follow `stride` floats apart
+  uint32_t stride;
+};
+template <typename R>
+__device__ __forceinline__ void deposit(const StoreSink& k, V3<R> c) {
+  k.c[0] = (float)c.x;
+  k.c[k.stride] = (float)c.y;
+  k.c[2u * k.stride] = (float)c.z;
+}
+
 // What the shading of a hit leaves for the scatter step.
 template <typename R>
 struct Surface {
@@ -784,9 +803,9 @@ struct Surface {
 // Camera.scala:29-33): geometry, material record, texture.  Emission deposits and
 // ends the path (returns false); otherwise T is multiplied by the attenuation and
 // `sf` describes the surface for scatter_direction().
-template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
-__device__ __forceinline__ bool shade_surface(const Scene& sc, const RenderArgs& A, const Ray<R>& ray,
-                                              const Trav<R>& tv, V3<R>& T, const Sink& sink,
+template <typename R, bool CNT, uint32_t FEAT, bool WIDE, typename SinkT>
+__device__ __forceinline__ bool shade_surface(const Scene& sc, const uint32_t* __restrict__ texels, const Ray<R>& ray,
+                                              const Trav<R>& tv, V3<R>& T, const SinkT& sink,
                                               Surface<R>& sf, Cnt& cnt) {
   HitGeom<R> h = hit_geometry<R, WIDE>(sc, ray, tv.best_t, tv.best_ref);
   typename M<R>::R4 m = load_r4<R>(sc, sc.L.mat, h.meta >> META_MAT_SHIFT);
@@ -804,7 +823,7 @@ __device__ __forceinline__ bool shade_surface(const Scene& sc, const RenderArgs&
     col = mk<R>(t.x, t.y, t.z);
     if (CNT) cnt.v[CTR_TEX0]++;
   } else {
-    col = texture_eval<R, CNT, FEAT>(sc, A.texels, tex, ray, h, cnt);
+    col = texture_eval<R, CNT, FEAT>(sc, texels, tex, ray, h, cnt);
   }
   if (sf.mkind == 3u) {  // Emission: never scatters, emits on both faces
     deposit<R>(sink, T * (sf.param * col));
@@ -857,8 +876,8 @@ __device__ __forceinline__ bool scatter_direction(const Surface<R>& sf, const Ra
 
 // Camera.get_ray (Camera.scala:19-23) for one sample of pixel (i, j)
 // (main.scala:88-89); rnd = the path's camera event.
-template <typename R, typename CamPtr>
-__device__ __forceinline__ void camera_ray(const RenderArgs& A, CamPtr camp, Ray<R>& ray,
+template <typename R, typename ArgsT, typename CamPtr>
+__device__ __forceinline__ void camera_ray(const ArgsT& A, CamPtr camp, Ray<R>& ray,
                                            uint32_t i, uint32_t j, const uint32_t rnd[4]) {
   const auto& cam = *camp;
   R xi1 = (R)0.5, xi2 = (R)0.5;
@@ -1039,7 +1058,7 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
         const V3<R> bg = mk<R>(cp->background[0], cp->background[1], cp->background[2]);
         deposit<R>(sink, T * bg);  // case None => background (Camera.scala:34)
         if (CNT) cnt.v[CTR_MISS]++;
-      } else if (shade_surface<R, CNT, FEAT, WIDE>(sc, A, ray, tv, T, sink, sf, cnt)) {
+      } else if (shade_surface<R, CNT, FEAT, WIDE>(sc, A.texels, ray, tv, T, sink, sf, cnt)) {
         // depth exhausted: the scattered ray's ray_color returns 0 (Camera.scala:27),
         // so the path contributes nothing more
         scatter = bounce < (uint32_t)A.max_depth;
@@ -1127,7 +1146,7 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
       philox4x32_10_keyed(pixel, sample, bounce, 0u, kernarg_args()->philox_keys, rnd);
       bool go = true;
       if (camera) {
-        camera_ray<R>(A, kernarg_camera<R>(), ray, cpx, cpy, rnd);
+        camera_ray<R, RenderArgs>(A, kernarg_camera<R>(), ray, cpx, cpy, rnd);
         T = mk<R>((R)1, (R)1, (R)1);
       } else {
         V3<R> dir;
@@ -1247,7 +1266,7 @@ __global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, Cam
   ra.H = A.H;
   const uint32_t no_rnd[4] = {0u, 0u, 0u, 0u};
   Ray<R> ray;
-  camera_ray<R>(ra, &cam, ray, px, py, no_rnd);  // jitter off: pixel centre, lens closed
+  camera_ray<R, RenderArgs>(ra, &cam, ray, px, py, no_rnd);  // jitter off: pixel centre, lens closed
   ray_setup<R>(ray);
   Trav<R> tv;
   trace_closest<R, WIDE>(sc, ray, tv, lds, stack_level0 + BT * (uint32_t)sizeof(stack_t), (R)0.001);
@@ -1295,6 +1314,225 @@ __global__ void resolve_kernel(const long long* __restrict__ accum, int32_t W, i
 __global__ void accum_add_kernel(long long* __restrict__ dst, const long long* __restrict__ src, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] += src[i];
+}
+
+
+// ---------------------------------------------------------------------------
+// wavefront variant: generate -> trace -> shade (+ compaction) -> ... -> reduce
+// ---------------------------------------------------------------------------
+// The same paths as render_kernel (same Philox counters, same arithmetic), cut into one
+// kernel per stage with the path state in global memory between them.  What it buys is
+// full waves in every stage: the trace stage refills idle lanes from the list of rays, the
+// shade stage runs one thread per path and writes the surviving paths compacted.  What it
+// costs is the traffic of the path state (about 180 bytes per ray) and of the per-path
+// contributions.  Built so that the two designs can be measured against each other.
+template <typename ArgsT>
+__device__ __forceinline__ void wf_pixel_of(const ArgsT& A, uint32_t item, uint32_t& pixel, uint32_t& sample) {
+  const uint32_t s = item / A.WH;
+  pixel = item - s * A.WH;
+  sample = (uint32_t)A.sample_first + s;
+}
+
+// Camera paths for items [item0, item0 + n_new) into slots [slot0, ...) of `cur`.
+__global__ void __launch_bounds__(256) wf_generate_kernel(WfArgs A, CamDev<float> cam) {
+  const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+  if (g >= A.n_new) return;
+  const uint32_t item = A.item0 + g, slot = A.slot0 + g;
+  uint32_t pixel, sample;
+  wf_pixel_of(A, item, pixel, sample);
+  const uint32_t py = pixel / (uint32_t)A.W, px = pixel - py * (uint32_t)A.W;
+  uint32_t rnd[4];
+  philox4x32_10_keyed(pixel, sample, 0u, 0u, A.philox_keys, rnd);
+  Ray<float> ray;
+  camera_ray<float, WfArgs>(A, &cam, ray, px, py, rnd);
+  const uint32_t cap = A.cap;
+  A.cur.ray[slot] = ray.o.x; A.cur.ray[cap + slot] = ray.o.y; A.cur.ray[2u * cap + slot] = ray.o.z;
+  A.cur.ray[3u * cap + slot] = ray.d.x; A.cur.ray[4u * cap + slot] = ray.d.y; A.cur.ray[5u * cap + slot] = ray.d.z;
+  A.cur.thr[slot] = 1.0f; A.cur.thr[cap + slot] = 1.0f; A.cur.thr[2u * cap + slot] = 1.0f;
+  A.cur.ids[slot] = item;
+  A.cur.ids[cap + slot] = 1u;  // bounce counter after the camera event, as in render_kernel
+}
+
+// Closest hit of rays [0, n) of `cur`.  Persistent waves: a lane whose ray is finished
+// keeps its result until the wave refills, which it does as soon as REFILL lanes are idle
+// (one atomic per wave on the ray counter); the traversal is render_kernel's.
+template <bool WIDE, bool TRIS>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6)))
+wf_trace_kernel(WfArgs A) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  typedef RefT<WIDE> RF;
+  typedef typename RF::stack_t stack_t;
+  const uint32_t BT = blockDim.x;
+  Scene sc;
+  sc.L = A.L;
+  uint32_t lds_image = 0;
+  if constexpr (WIDE) {
+    sc.base = A.blob;
+  } else {
+    copy_scene_to_lds(lds, A.blob, A.L.total_bytes, BT);
+    sc.base = lds;
+    lds_image = A.L.total_bytes;
+  }
+  const uint32_t stack_level0 = lds_image + threadIdx.x * (uint32_t)sizeof(stack_t);
+  const uint32_t stack_level1 = stack_level0 + BT * (uint32_t)sizeof(stack_t);
+  *(stack_t*)(lds + stack_level0) = (stack_t)RF::EMPTY;
+  const uint32_t lane = threadIdx.x & 63u;
+  const float t_min = 0.001f;
+  const int REFILL = A.refill;  // idle lanes that trigger a refill
+  Cnt cnt;
+  Ray<float> ray;
+  ray.o = ray.d = ray.inv = mk<float>(0.f, 0.f, 0.f);
+  ray.a = ray.inv_a = ray.oo = 0.f;
+  Trav<float> tv;
+  trav_begin<float, WIDE>(tv, stack_level1);
+  tv.cur = RF::EMPTY;
+  uint32_t my_ray = 0xFFFFFFFFu;
+  bool list_empty = false;
+  const uint32_t cap = A.cap, n = A.n;
+  // The wave's block of the ray list, [blk_next, blk_end): one atomic on the shared counter
+  // reserves a block (a single word takes about 90 atomics per microsecond, far fewer than
+  // the refills of six thousand waves), and the refills hand it out 64 rays or fewer at a time.
+  uint32_t blk_next = 0, blk_end = 0;
+  const uint32_t n_waves = gridDim.x * (BT >> 6);
+  for (;;) {
+    const uint64_t idle = __ballot(tv.cur == RF::EMPTY);
+    const int n_idle = __popcll(idle);
+    if (n_idle >= REFILL && !(list_empty && n_idle < 64)) {
+      // results of the finished rays
+      if (tv.cur == RF::EMPTY && my_ray != 0xFFFFFFFFu) {
+        A.hit_t[my_ray] = tv.best_t;
+        A.hit_ref[my_ray] = tv.best_ref;
+        my_ray = 0xFFFFFFFFu;
+      }
+      if (list_empty) break;  // every lane idle and nothing left to take
+      if (blk_next >= blk_end) {
+        // an even share of the list in eight blocks per wave, 64..4096 rays
+        uint32_t want = min(4096u, max(64u, (n / n_waves / 8u + 63u) & ~63u));
+        if (lane == 0) blk_next = atomicAdd(A.counters + 1, want);
+        blk_next = __builtin_amdgcn_readfirstlane(blk_next);
+        want = __builtin_amdgcn_readfirstlane(want);
+        blk_end = min(n, blk_next + want);
+        if (blk_next >= n) {
+          list_empty = true;
+          blk_next = blk_end = 0;
+          continue;
+        }
+      }
+      if (tv.cur == RF::EMPTY) {
+        const uint32_t idx = blk_next + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+        if (idx < blk_end) {
+          ray.o = mk<float>(A.cur.ray[idx], A.cur.ray[cap + idx], A.cur.ray[2u * cap + idx]);
+          ray.d = mk<float>(A.cur.ray[3u * cap + idx], A.cur.ray[4u * cap + idx], A.cur.ray[5u * cap + idx]);
+          ray_setup<float>(ray);
+          ray_start<float, false, WIDE>(sc, ray, tv, stack_level1, t_min, cnt);
+          my_ray = idx;
+        }
+      }
+      blk_next = min(blk_end, blk_next + (uint32_t)n_idle);
+      continue;
+    }
+    // node steps while at least half of the travelling lanes are at inner nodes, then one
+    // leaf step, as in render_kernel
+    for (;;) {
+      const bool inner = tv.cur < RF::LEAF;
+      const uint64_t mi = __ballot(inner);
+      const uint64_t mt = __ballot(tv.cur != RF::EMPTY);
+      if (mi == 0ull || 2 * __popcll(mi) < __popcll(mt)) break;
+      if (inner) node_step<float, false, WIDE>(sc, ray, tv, lds, t_min, cnt);
+      if (tv.cur < RF::LEAF) node_step<float, false, WIDE>(sc, ray, tv, lds, t_min, cnt);
+    }
+    const bool leaf = (uint32_t)(tv.cur - RF::LEAF) < (RF::EMPTY - RF::LEAF);
+    if (leaf) {
+      leaf_test<float, false, WIDE, TRIS>(sc, ray, tv, tv.cur, t_min, cnt);
+      tv.cur = trav_pop<float, WIDE>(tv, lds);
+    }
+  }
+}
+
+// One thread per path of `cur`: deposit or scatter (Camera.scala:29-34, Material.scala:9-55);
+// the paths that go on are written to `nxt` without gaps (one atomic per wave).
+template <uint32_t FEAT, bool WIDE>
+__global__ void __launch_bounds__(1024) wf_shade_kernel(WfArgs A, CamDev<float> cam) {
+  typedef RefT<WIDE> RF;
+  const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t cap = A.cap;
+  Scene sc;
+  sc.L = A.L;
+  sc.base = A.blob;  // shading touches one primitive, one material and its textures: read in place
+  bool go = false;
+  Ray<float> ray;
+  V3<float> T = mk<float>(1.f, 1.f, 1.f), dir = mk<float>(0.f, 0.f, 0.f);
+  Surface<float> sf;
+  sf.p = sf.n = mk<float>(0.f, 0.f, 0.f);
+  sf.param = 0.f; sf.mkind = 0u; sf.front = false;
+  uint32_t item = 0, bounce = 0;
+  if (i < A.n) {
+    ray.o = mk<float>(A.cur.ray[i], A.cur.ray[cap + i], A.cur.ray[2u * cap + i]);
+    ray.d = mk<float>(A.cur.ray[3u * cap + i], A.cur.ray[4u * cap + i], A.cur.ray[5u * cap + i]);
+    ray_setup<float>(ray);
+    T = mk<float>(A.cur.thr[i], A.cur.thr[cap + i], A.cur.thr[2u * cap + i]);
+    item = A.cur.ids[i];
+    bounce = A.cur.ids[cap + i];
+    Trav<float> tv;
+    tv.cur = RF::EMPTY;
+    tv.sp = 0;
+    tv.best_t = A.hit_t[i];
+    tv.best_ref = A.hit_ref[i];
+    StoreSink sink;
+    sink.c = A.contrib + item;
+    sink.stride = A.items;
+    Cnt cnt;
+    bool scatter = false;
+    if (tv.best_ref == RF::EMPTY) {
+      deposit<float>(sink, T * mk<float>(cam.background[0], cam.background[1], cam.background[2]));
+    } else if (shade_surface<float, false, FEAT, WIDE>(sc, A.texels, ray, tv, T, sink, sf, cnt)) {
+      scatter = bounce < (uint32_t)A.max_depth;
+    }
+    if (scatter) {
+      uint32_t pixel, sample, rnd[4];
+      wf_pixel_of(A, item, pixel, sample);
+      philox4x32_10_keyed(pixel, sample, bounce, 0u, A.philox_keys, rnd);
+      go = scatter_direction<float>(sf, ray, rnd, dir, sc.L.scatter_diffuse_only != 0u);
+    }
+  }
+  // compaction: the waves' survivor counts meet in LDS and one lane of the workgroup takes
+  // the block of `nxt` for all of them (one atomic per 1024 paths on the shared counter)
+  __shared__ uint32_t wave_count[16], wave_base[16];
+  const uint64_t alive = __ballot(go);
+  const uint32_t wave = threadIdx.x >> 6;
+  if (lane == 0) wave_count[wave] = (uint32_t)__popcll(alive);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) { wave_base[w] = total; total += wave_count[w]; }
+    const uint32_t start = total ? atomicAdd(A.counters, total) : 0u;
+    for (uint32_t w = 0; w < (blockDim.x >> 6); ++w) wave_base[w] += start;
+  }
+  __syncthreads();
+  const uint32_t base = wave_base[wave];
+  if (go) {
+    const uint32_t o = base + (uint32_t)__popcll(alive & ((1ull << lane) - 1ull));
+    A.nxt.ray[o] = sf.p.x; A.nxt.ray[cap + o] = sf.p.y; A.nxt.ray[2u * cap + o] = sf.p.z;
+    A.nxt.ray[3u * cap + o] = dir.x; A.nxt.ray[4u * cap + o] = dir.y; A.nxt.ray[5u * cap + o] = dir.z;
+    A.nxt.thr[o] = T.x; A.nxt.thr[cap + o] = T.y; A.nxt.thr[2u * cap + o] = T.z;
+    A.nxt.ids[o] = item;
+    A.nxt.ids[cap + o] = bounce + 1u;
+  }
+}
+
+// accum[pixel][c] += sum over the launch's samples of the stored contributions, converted to
+// fixed point one by one exactly as render_kernel's deposits are.
+__global__ void __launch_bounds__(256) wf_reduce_kernel(WfArgs A, uint32_t samples) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= A.WH) return;
+#pragma unroll
+  for (uint32_t c = 0; c < 3u; ++c) {
+    const float* src = A.contrib + (size_t)c * A.items + p;
+    long long sum = 0;
+    for (uint32_t s = 0; s < samples; ++s) sum += to_fixed<float>(src[(size_t)s * A.WH]);
+    A.accum[(size_t)p * 3u + c] += sum;
+  }
 }
 
 // dst[i] += src[0][i] + src[1][i] + ... : one slice of the frame, `count` copies n words apart
@@ -1432,6 +1670,52 @@ hipError_t launch_first_hit(int precision, const FirstHitArgs& a, const void* ca
                     : launch_first_hit_t<float, false>(a, cam, blocks, threads, lds_bytes, stream);
   return a.L.wide ? launch_first_hit_t<double, true>(a, cam, blocks, threads, lds_bytes, stream)
                   : launch_first_hit_t<double, false>(a, cam, blocks, threads, lds_bytes, stream);
+}
+
+
+hipError_t launch_wf_generate(const WfArgs& a, const CamDev<float>& cam, hipStream_t stream) {
+  if (a.n_new == 0) return hipSuccess;
+  hipLaunchKernelGGL(wf_generate_kernel, dim3((a.n_new + 255u) / 256u), dim3(256), 0, stream, a, cam);
+  return hipGetLastError();
+}
+
+template <bool WIDE, bool TRIS>
+static hipError_t launch_wf_trace_t(const WfArgs& a, int grid_blocks, int threads, uint32_t lds_bytes, hipStream_t stream) {
+  if (lds_bytes > LDS_LIMIT_BYTES) return hipErrorInvalidValue;
+  hipError_t e = allow_big_lds(wf_trace_kernel<WIDE, TRIS>, LDS_LIMIT_BYTES);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((wf_trace_kernel<WIDE, TRIS>), dim3(grid_blocks), dim3(threads), lds_bytes, stream, a);
+  return hipGetLastError();
+}
+hipError_t launch_wf_trace(uint32_t feat, const WfArgs& a, int grid_blocks, int threads, uint32_t lds_bytes,
+                           hipStream_t stream) {
+  if (a.n == 0) return hipSuccess;
+  const bool tris = (feat & KFEAT_TRIS) != 0u;
+  if (a.L.wide) return tris ? launch_wf_trace_t<true, true>(a, grid_blocks, threads, lds_bytes, stream)
+                            : launch_wf_trace_t<true, false>(a, grid_blocks, threads, lds_bytes, stream);
+  return tris ? launch_wf_trace_t<false, true>(a, grid_blocks, threads, lds_bytes, stream)
+              : launch_wf_trace_t<false, false>(a, grid_blocks, threads, lds_bytes, stream);
+}
+
+template <bool WIDE>
+static hipError_t launch_wf_shade_t(uint32_t feat, const WfArgs& a, const CamDev<float>& cam, hipStream_t stream) {
+  const dim3 grid((a.n + 1023u) / 1024u), block(1024);
+  switch (feat & 3u) {
+    case 0: hipLaunchKernelGGL((wf_shade_kernel<0u, WIDE>), grid, block, 0, stream, a, cam); break;
+    case 1: hipLaunchKernelGGL((wf_shade_kernel<1u, WIDE>), grid, block, 0, stream, a, cam); break;
+    case 2: hipLaunchKernelGGL((wf_shade_kernel<2u, WIDE>), grid, block, 0, stream, a, cam); break;
+    default: hipLaunchKernelGGL((wf_shade_kernel<3u, WIDE>), grid, block, 0, stream, a, cam); break;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_wf_shade(uint32_t feat, const WfArgs& a, const CamDev<float>& cam, hipStream_t stream) {
+  if (a.n == 0) return hipSuccess;
+  return a.L.wide ? launch_wf_shade_t<true>(feat, a, cam, stream) : launch_wf_shade_t<false>(feat, a, cam, stream);
+}
+
+hipError_t launch_wf_reduce(const WfArgs& a, uint32_t samples, hipStream_t stream) {
+  hipLaunchKernelGGL(wf_reduce_kernel, dim3((a.WH + 255u) / 256u), dim3(256), 0, stream, a, samples);
+  return hipGetLastError();
 }
 
 hipError_t launch_accum_add(long long* dst, const long long* src, size_t n, hipStream_t stream) {
