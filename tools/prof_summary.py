@@ -14,7 +14,7 @@ for f in glob.glob(f"{base}/trace_{tag}/*/*_kernel_stats.csv"):
     for r in csv.DictReader(open(f)):
         print(f"{r['Name'][:90]:90s} calls={r['Calls']:>4s} total_ms={float(r['TotalDurationNs'])/1e6:10.3f} "
               f"avg_ms={float(r['AverageNs'])/1e6:9.4f} pct={float(r['Percentage']):6.2f}")
-print(f"\n## PMC passes (one rocprofv3 --pmc run each): bench.py --workload {wl} --steps 1 --warmup 0 --spp 256 --no-cpu-baseline")
+print(f"\n## PMC passes (one rocprofv3 --pmc run each): bench.py --workload {wl} --steps 1 --warmup 0 --spp <samples per launch, default 1024> --no-cpu-baseline")
 print("## values are sums over the dispatches of the kernel in that run")
 for n in (1, 2, 3, 4, 5, 6, 7, 8):
     for f in glob.glob(f"{base}/pmc{n}_{tag}/*/*_counter_collection.csv"):

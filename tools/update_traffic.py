@@ -34,7 +34,7 @@ def counter(pass_no, name):
 path = os.path.join(ROOT, "profiles", "traffic.json")
 data = json.load(open(path))
 data[workload] = {
-    "spp_per_launch": 256,
+    "spp_per_launch": int(open(f"{base}/spp_per_launch_{tag}.txt").read()),
     "fetch_bytes": int(counter(3, "FETCH_SIZE") * 1024),
     "write_bytes": int(counter(4, "WRITE_SIZE") * 1024),
     "kernels_hip_sha16": open(f"{base}/kernels_hip_sha16_{tag}.txt").read().strip(),
