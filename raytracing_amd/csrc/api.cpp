@@ -109,8 +109,8 @@ std::atomic<int> g_chunk{0};  // 0: by launch size
 std::atomic<int> g_chunk_tail{4};
 std::atomic<int> g_force_hbm{0};     // scenes created while set keep their image in HBM
 std::atomic<int> g_wavefront{0};      // 1: fp32 renders run the wavefront variant
-std::atomic<int> g_wavefront_cap{1 << 24};
-std::atomic<int> g_wavefront_refill{32};  // paths in flight of the wavefront variant
+std::atomic<int> g_wavefront_cap{1 << 24};  // paths in flight of the wavefront variant
+std::atomic<int> g_wavefront_refill{32};    // idle lanes of a trace wave that trigger a refill
 std::atomic<int> g_shape_generation{0};  // bumped by the options a launch shape depends on
 
 // Makes `device` current for the lifetime of the object, then restores.
