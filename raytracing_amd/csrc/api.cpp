@@ -261,6 +261,8 @@ int make_plan(ht_scene* s, const ht_camera* cam, const ht_render_params* p, int6
   a.node_den = g_node_den.load();
   a.wait_ratio_num = g_wait_num.load();
   a.wait_ratio_den = g_wait_den.load();
+  a.inv_w1 = 1.0f / (float)(p->width - 1);
+  a.inv_h1 = 1.0f / (float)(p->height - 1);
 
   int batch = p->batch > 0 ? p->batch : g_default_batch.load();
   // the work queue of one launch is indexed with 32 bits: tiles x sample chunks
@@ -322,6 +324,8 @@ int render_wavefront(ht_scene* s, const RenderPlan& pl, int first, int count, hi
     a.max_depth = ra.max_depth;
     a.jitter = ra.jitter;
     a.refill = g_wavefront_refill.load();
+    a.inv_w1 = ra.inv_w1;
+    a.inv_h1 = ra.inv_h1;
     memcpy(a.philox_keys, ra.philox_keys, sizeof a.philox_keys);
     float* w = (float*)s->d_wf;
     WfBuffers b0, b1;

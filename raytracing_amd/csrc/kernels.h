@@ -38,6 +38,7 @@ struct RenderArgs {
   int32_t wait_threshold;  // lanes that may wait for shading before traversal yields
   int32_t node_den;        // node steps go on while inner lanes * node_den >= travelling lanes
   int32_t wait_ratio_num, wait_ratio_den;  // traversal also yields when waiting/travelling >= num/den
+  float inv_w1, inv_h1;    // 1/(W-1), 1/(H-1) correctly rounded (jittered fp32 sample positions)
 };
 
 // ---- wavefront variant: the same paths as render_kernel, one kernel per stage ----------
@@ -71,6 +72,7 @@ struct WfArgs {
   int32_t W, H;
   int32_t sample_first;   // global index of the launch's first sample
   int32_t max_depth, jitter;
+  float inv_w1, inv_h1;   // 1/(W-1), 1/(H-1)
   int32_t refill;         // trace: idle lanes of a wave that trigger a refill from the ray list
   uint32_t philox_keys[20];
 };

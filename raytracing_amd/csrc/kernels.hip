@@ -878,7 +878,8 @@ __device__ __forceinline__ bool scatter_direction(const Surface<R>& sf, const Ra
 // (main.scala:88-89); rnd = the path's camera event.
 template <typename R, typename ArgsT, typename CamPtr>
 __device__ __forceinline__ void camera_ray(const ArgsT& A, CamPtr camp, Ray<R>& ray,
-                                           uint32_t i, uint32_t j, const uint32_t rnd[4]) {
+                                           uint32_t i, uint32_t j, const uint32_t rnd[4],
+                                           float inv_w1, float inv_h1) {
   const auto& cam = *camp;
   R xi1 = (R)0.5, xi2 = (R)0.5;
   V3<R> offset = mk<R>((R)0, (R)0, (R)0);
@@ -891,10 +892,19 @@ __device__ __forceinline__ void camera_ray(const ArgsT& A, CamPtr camp, Ray<R>& 
     M<R>::sincos2pi(u01<R>(rnd[3]), s, c);
     offset = (r * c) * ld3<R>(cam.u) + (r * s) * ld3<R>(cam.v);
   }
-  // a true division, as main.scala:88-89 has it: a reciprocal and a multiply would save
-  // ~30 instructions per camera ray, and move pixel-centre rays across texel boundaries
-  R s = ((R)i + xi1) / (R)(A.W - 1);
-  R t = ((R)j + xi2) / (R)(A.H - 1);
+  // main.scala:88-89 divides.  With the jitter off the division is kept: a reciprocal and a
+  // multiply move pixel-centre rays across texel boundaries (24 of 2304 pixels of plane.json).
+  // A jittered fp32 sample position is a random number whose last bit carries nothing (i + xi
+  // has already lost eleven bits of xi at i ~ 1900), so there the host's correctly rounded
+  // 1/(W-1), 1/(H-1) are multiplied in: ~30 instructions fewer per camera ray.
+  R s, t;
+  if (sizeof(R) == 4 && A.jitter) {
+    s = ((R)i + xi1) * (R)inv_w1;
+    t = ((R)j + xi2) * (R)inv_h1;
+  } else {
+    s = ((R)i + xi1) / (R)(A.W - 1);
+    t = ((R)j + xi2) / (R)(A.H - 1);
+  }
   V3<R> origin = ld3<R>(cam.origin);
   ray.o = origin + offset;
   ray.d = (ld3<R>(cam.corner) + s * ld3<R>(cam.horizontal) + t * ld3<R>(cam.vertical)) - offset;
@@ -1146,7 +1156,10 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
       philox4x32_10_keyed(pixel, sample, bounce, 0u, kernarg_args()->philox_keys, rnd);
       bool go = true;
       if (camera) {
-        camera_ray<R, RenderArgs>(A, kernarg_camera<R>(), ray, cpx, cpy, rnd);
+        {
+          const auto* ca = kernarg_args();
+          camera_ray<R, RenderArgs>(A, kernarg_camera<R>(), ray, cpx, cpy, rnd, ca->inv_w1, ca->inv_h1);
+        }
         T = mk<R>((R)1, (R)1, (R)1);
       } else {
         V3<R> dir;
@@ -1266,7 +1279,7 @@ __global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, Cam
   ra.H = A.H;
   const uint32_t no_rnd[4] = {0u, 0u, 0u, 0u};
   Ray<R> ray;
-  camera_ray<R, RenderArgs>(ra, &cam, ray, px, py, no_rnd);  // jitter off: pixel centre, lens closed
+  camera_ray<R, RenderArgs>(ra, &cam, ray, px, py, no_rnd, 0.f, 0.f);  // jitter off: pixel centre, lens closed
   ray_setup<R>(ray);
   Trav<R> tv;
   trace_closest<R, WIDE>(sc, ray, tv, lds, stack_level0 + BT * (uint32_t)sizeof(stack_t), (R)0.001);
@@ -1344,7 +1357,7 @@ __global__ void __launch_bounds__(256) wf_generate_kernel(WfArgs A, CamDev<float
   uint32_t rnd[4];
   philox4x32_10_keyed(pixel, sample, 0u, 0u, A.philox_keys, rnd);
   Ray<float> ray;
-  camera_ray<float, WfArgs>(A, &cam, ray, px, py, rnd);
+  camera_ray<float, WfArgs>(A, &cam, ray, px, py, rnd, A.inv_w1, A.inv_h1);
   const uint32_t cap = A.cap;
   A.cur.ray[slot] = ray.o.x; A.cur.ray[cap + slot] = ray.o.y; A.cur.ray[2u * cap + slot] = ray.o.z;
   A.cur.ray[3u * cap + slot] = ray.d.x; A.cur.ray[4u * cap + slot] = ray.d.y; A.cur.ray[5u * cap + slot] = ray.d.z;
