@@ -1025,20 +1025,17 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
   tv.cur = RF::EMPTY;
   *(stack_t*)(lds + stack_level0) = (stack_t)RF::EMPTY;
 
-  // Adds the wave's tile sums to the frame and clears them.  The tile's 192 sums (8 rows of
-  // 8 pixels x 3 channels) are taken in memory order, 64 consecutive words per instruction:
-  // a row of the tile is 24 consecutive words of the frame, so one instruction's atomics
-  // fall into runs of 192 contiguous bytes instead of 64 words 24 bytes apart.
+  // adds the wave's tile sums to the frame and clears them
   auto flush_tile = [&]() {
+    const uint32_t px = tile_x0 + (lane & 7u), py = tile_y0 + (lane >> 3);
+    if (px < (uint32_t)A.W && py < (uint32_t)A.H) {
+      unsigned long long* out = frame + ((size_t)py * (uint32_t)A.W + px) * 3u;
 #pragma unroll
-    for (uint32_t k = 0; k < 3u; ++k) {
-      const uint32_t w = k * 64u + lane;          // word of the tile: (row * 8 + px) * 3 + channel
-      const uint32_t row = w / 24u, cw = w - row * 24u;
-      const uint32_t px = tile_x0 + cw / 3u, py = tile_y0 + row;
-      const unsigned long long v = tile_acc[w];
-      tile_acc[w] = 0ull;
-      if (v != 0ull && px < (uint32_t)A.W && py < (uint32_t)A.H)
-        atomicAdd(frame + ((size_t)py * (uint32_t)A.W + tile_x0) * 3u + cw, v);
+      for (uint32_t c = 0; c < 3u; ++c) {
+        const unsigned long long v = tile_acc[lane * 3u + c];
+        if (v != 0ull) atomicAdd(out + c, v);
+        tile_acc[lane * 3u + c] = 0ull;
+      }
     }
   };
 
