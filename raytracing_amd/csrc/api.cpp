@@ -190,6 +190,12 @@ int launch_shape(ht_scene* s, int prec, bool counters, LaunchShape& out) {
       // several workgroups share a CU well only when each fills the four SIMDs evenly: two
       // groups of 14 waves (measured on the Cornell box) ran 20 % slower than two of 12
       if (b > 1 && t % 256 != 0) b = 1;
+      // The render kernels use 95 to 105 scalar registers, and a SIMD admits at most seven
+      // waves of a kernel that uses 81 to 96 (fewer beyond; the occupancy API does not know and
+      // answers eight): a second 1024-thread workgroup that the API promises never becomes
+      // resident (measured on the dragon: "1024 x 2" 20.1, 768 x 2 24.3 G samples/s).
+      constexpr int MAX_WAVES_PER_CU = 28;
+      if (b * t > MAX_WAVES_PER_CU * 64) b = MAX_WAVES_PER_CU * 64 / t;
       if (b * t > best.bpc * best.threads) { best.threads = t; best.bpc = b; best.lds = need; }
     }
     best.generation = gen;

@@ -87,6 +87,9 @@ struct Builder {
   HostScene& hs;
   std::vector<Item>& items;
   int max_level = 0;
+  // leaves of two triangles: (kind-local index of the first, of the second); a pair's
+  // reference carries its position in this list until the triangles are renumbered
+  std::vector<std::pair<uint32_t, uint32_t>> pairs;
 
   static constexpr int NBINS = 16;
 
@@ -96,6 +99,15 @@ struct Builder {
     if (n == 1) {
       out_box = items[begin].box;
       return items[begin].ref;
+    }
+    // two triangles below an inner node become one leaf: the node that would separate them
+    // costs a visit of its own, more than testing the second triangle outright
+    if (n == 2 && level > 0 && ((items[begin].ref >> WREF_KIND_SHIFT) & 7u) == KIND_TRIANGLE &&
+        ((items[begin + 1].ref >> WREF_KIND_SHIFT) & 7u) == KIND_TRIANGLE) {
+      out_box = items[begin].box;
+      out_box.grow(items[begin + 1].box);
+      pairs.emplace_back(items[begin].ref & WREF_INDEX_MASK, items[begin + 1].ref & WREF_INDEX_MASK);
+      return WREF_LEAF | (KIND_TRI_PAIR << WREF_KIND_SHIFT) | (uint32_t)(pairs.size() - 1);
     }
     const uint32_t idx = (uint32_t)hs.nodes.size();
     hs.nodes.emplace_back();
@@ -664,6 +676,38 @@ int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err, co
     wide_levels = std::min(WIDE_STACK_MAX_DEPTH, std::max(18, wide_levels));
     b.build(0, nb, small ? STACK_MAX_DEPTH : wide_levels, 0, rb);
     hs.depth = b.max_level;
+    if (!b.pairs.empty()) {
+      // the two triangles of a pair must be neighbours in the triangle array: pairs first,
+      // in the order the builder made them, then every other triangle in its old order
+      const size_t nt = hs.tri.size();
+      std::vector<uint32_t> new_index(nt, 0xFFFFFFFFu);
+      std::vector<int32_t> new_tri;
+      new_tri.reserve(nt);
+      std::vector<uint32_t> pair_first(b.pairs.size());
+      for (size_t k = 0; k < b.pairs.size(); ++k) {
+        pair_first[k] = (uint32_t)new_tri.size();
+        for (uint32_t old : {b.pairs[k].first, b.pairs[k].second}) {
+          new_index[old] = (uint32_t)new_tri.size();
+          new_tri.push_back(hs.tri[old]);
+        }
+      }
+      for (size_t old = 0; old < nt; ++old)
+        if (new_index[old] == 0xFFFFFFFFu) {
+          new_index[old] = (uint32_t)new_tri.size();
+          new_tri.push_back(hs.tri[old]);
+        }
+      hs.tri.swap(new_tri);
+      auto renumber = [&](uint32_t r) -> uint32_t {
+        if (!(r & WREF_LEAF) || r == WREF_EMPTY) return r;
+        const uint32_t kind = (r >> WREF_KIND_SHIFT) & 7u, i = r & WREF_INDEX_MASK;
+        if (kind == KIND_TRIANGLE) return (r & ~WREF_INDEX_MASK) | new_index[i];
+        if (kind == KIND_TRI_PAIR) return (r & ~WREF_INDEX_MASK) | pair_first[i];
+        return r;
+      };
+      for (auto& nd : hs.nodes) { nd.child[0] = renumber(nd.child[0]); nd.child[1] = renumber(nd.child[1]); }
+      for (auto& r : hs.hoist) r = renumber(r);
+      for (auto& r : hs.prim_ref) r = renumber(r);
+    }
   }
   for (int a = 0; a < 3; ++a) {
     hs.root_lo[a] = nb ? root.lo[a] : 0.0;

@@ -439,6 +439,15 @@ __device__ __forceinline__ void triangle_test(const Scene& sc, const Ray<R>& ray
   tv.best_t = ok ? t : tv.best_t;
   tv.best_ref = ok ? ref : tv.best_ref;
 }
+// A triangle leaf: triangle idx, and for a pair (KIND_TRI_PAIR) triangle idx + 1 as well.  The
+// hit is recorded under the single triangle's own reference.
+template <typename R, bool CNT, bool WIDE>
+__device__ __forceinline__ void triangle_pair_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t idx,
+                                                   bool pair, R t_min, Cnt& cnt) {
+  const uint32_t single = RefT<WIDE>::LEAF | (KIND_TRIANGLE << RefT<WIDE>::KIND_SHIFT);
+  triangle_test<R, CNT>(sc, ray, tv, single | idx, idx, t_min, cnt);
+  if (pair) triangle_test<R, CNT>(sc, ray, tv, single | (idx + 1u), idx + 1u, t_min, cnt);
+}
 template <typename R, bool CNT>
 __device__ __forceinline__ void rect_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t ref,
                                           uint32_t kind, uint32_t idx, R t_min, Cnt& cnt) {
@@ -459,6 +468,7 @@ __device__ __forceinline__ void prim_test(const Scene& sc, const Ray<R>& ray, Tr
                                           R t_min, Cnt& cnt) {
   const uint32_t kind = (ref >> RefT<WIDE>::KIND_SHIFT) & 7u, idx = ref & RefT<WIDE>::INDEX_MASK;
   if (kind == KIND_TRIANGLE) triangle_test<R, CNT>(sc, ray, tv, ref, idx, t_min, cnt);
+  else if (kind == KIND_TRI_PAIR) triangle_pair_test<R, CNT, WIDE>(sc, ray, tv, idx, true, t_min, cnt);
   else if (kind == KIND_SPHERE || kind == KIND_BIG_SPHERE) sphere_test<R, CNT>(sc, ray, tv, ref, kind, idx, t_min, cnt);
   else rect_test<R, CNT>(sc, ray, tv, ref, kind, idx, t_min, cnt);
 }
@@ -469,7 +479,8 @@ template <typename R, bool CNT, bool WIDE, bool TRIS>
 __device__ __forceinline__ void leaf_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t ref,
                                           R t_min, Cnt& cnt) {
   const uint32_t idx = ref & RefT<WIDE>::INDEX_MASK;
-  if (TRIS || sc.L.tree_kinds == TREE_TRIANGLES) triangle_test<R, CNT>(sc, ray, tv, ref, idx, t_min, cnt);
+  if (TRIS || sc.L.tree_kinds == TREE_TRIANGLES)
+    triangle_pair_test<R, CNT, WIDE>(sc, ray, tv, idx, ((ref >> RefT<WIDE>::KIND_SHIFT) & 7u) == KIND_TRI_PAIR, t_min, cnt);
   else if (sc.L.tree_kinds == TREE_SPHERES) sphere_test<R, CNT>(sc, ray, tv, ref, KIND_SPHERE, idx, t_min, cnt);
   else prim_test<R, CNT, WIDE>(sc, ray, tv, ref, t_min, cnt);
 }

@@ -60,6 +60,10 @@ enum : uint32_t {
   KIND_TRIANGLE = 4,
   KIND_BIG_SPHERE = 5,  // c = |o|^2 - 2 o.c + K, K = |c|^2 - r^2 from the host in fp64:
                         // well conditioned when r dwarfs the rest of the scene
+  KIND_TRI_PAIR = 6,    // a leaf of two triangles, i and i + 1 of the triangle array: one node
+                        // visit fewer than two single leaves under a node of their own.  Only a
+                        // node's child is ever a pair; a closest hit is recorded as the single
+                        // triangle's reference.
 };
 // SceneLayout::tree_kinds.  TREE_SPHERES means ordinary spheres only: a KIND_BIG_SPHERE
 // inside the hierarchy sets TREE_MIXED as well, which sends leaves through the full dispatch.

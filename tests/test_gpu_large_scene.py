@@ -81,7 +81,7 @@ def test_large_mesh_goes_to_the_hbm_store(dev, mesh20k):
     with dev.Scene(flat, device=0) as s:
         info = s.info()
         assert info["hbm_store_fp32"] == 1 and info["hbm_store_fp64"] == 1
-        assert info["n_prims"] == flat.n_prims and info["n_nodes"] >= flat.n_prims - 10
+        assert info["n_prims"] == flat.n_prims and info["n_nodes"] >= flat.n_prims // 2 - 10  # two triangles per leaf
 
 
 def test_large_mesh_first_hit_fp64_matches_oracle(dev, oracle_mod, mesh20k):
