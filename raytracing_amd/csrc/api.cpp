@@ -102,6 +102,7 @@ int fail(int code, const char* fmt, ...) {
 // tuning knobs (ht_set_option)
 std::atomic<int> g_wait_threshold{40};
 std::atomic<int> g_max_blocks_per_cu{8};
+std::atomic<int> g_max_waves_per_cu{28};
 std::atomic<int> g_block_threads{0};  // 0: choose
 std::atomic<int> g_node_den{2}, g_wait_num{1000}, g_wait_den{1};
 std::atomic<int> g_default_batch{1024};
@@ -194,8 +195,8 @@ int launch_shape(ht_scene* s, int prec, bool counters, LaunchShape& out) {
       // waves of a kernel that uses 81 to 96 (fewer beyond; the occupancy API does not know and
       // answers eight): a second 1024-thread workgroup that the API promises never becomes
       // resident (measured on the dragon: "1024 x 2" 20.1, 768 x 2 24.3 G samples/s).
-      constexpr int MAX_WAVES_PER_CU = 28;
-      if (b * t > MAX_WAVES_PER_CU * 64) b = MAX_WAVES_PER_CU * 64 / t;
+      const int max_waves = g_max_waves_per_cu.load();
+      if (b * t > max_waves * 64) b = max_waves * 64 / t;
       if (b * t > best.bpc * best.threads) { best.threads = t; best.bpc = b; best.lds = need; }
     }
     best.generation = gen;
@@ -513,6 +514,7 @@ const char* ht_last_error(void) { return g_error; }
 int ht_set_option(const char* name, int value) {
   if (!name) return fail(HT_E_INVALID, "option name is NULL");
   if (!strcmp(name, "wait_threshold")) { g_wait_threshold = std::min(64, std::max(1, value)); return HT_OK; }
+  if (!strcmp(name, "max_waves_per_cu")) { g_max_waves_per_cu = std::min(32, std::max(4, value)); g_shape_generation++; return HT_OK; }
   if (!strcmp(name, "max_blocks_per_cu")) { g_max_blocks_per_cu = std::max(1, value); g_shape_generation++; return HT_OK; }
   if (!strcmp(name, "default_batch")) { g_default_batch = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "chunk")) { g_chunk = std::max(0, value); return HT_OK; }

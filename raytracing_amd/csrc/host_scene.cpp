@@ -87,9 +87,10 @@ struct Builder {
   HostScene& hs;
   std::vector<Item>& items;
   int max_level = 0;
-  // leaves of two triangles: (kind-local index of the first, of the second); a pair's
-  // reference carries its position in this list until the triangles are renumbered
-  std::vector<std::pair<uint32_t, uint32_t>> pairs;
+  // leaves of two triangles / two ordinary spheres: (kind-local index of the first, of the
+  // second); a pair's reference carries its position in the list of its kind until the
+  // primitives are renumbered
+  std::vector<std::pair<uint32_t, uint32_t>> pairs, sph_pairs;
 
   static constexpr int NBINS = 16;
 
@@ -100,14 +101,19 @@ struct Builder {
       out_box = items[begin].box;
       return items[begin].ref;
     }
-    // two triangles below an inner node become one leaf: the node that would separate them
-    // costs a visit of its own, more than testing the second triangle outright
-    if (n == 2 && level > 0 && ((items[begin].ref >> WREF_KIND_SHIFT) & 7u) == KIND_TRIANGLE &&
-        ((items[begin + 1].ref >> WREF_KIND_SHIFT) & 7u) == KIND_TRIANGLE) {
-      out_box = items[begin].box;
-      out_box.grow(items[begin + 1].box);
-      pairs.emplace_back(items[begin].ref & WREF_INDEX_MASK, items[begin + 1].ref & WREF_INDEX_MASK);
-      return WREF_LEAF | (KIND_TRI_PAIR << WREF_KIND_SHIFT) | (uint32_t)(pairs.size() - 1);
+    // two triangles (or two ordinary spheres) below an inner node become one leaf: the node
+    // that would separate them costs a visit of its own, more than testing the second
+    // primitive outright
+    if (n == 2 && level > 0) {
+      const uint32_t k0 = (items[begin].ref >> WREF_KIND_SHIFT) & 7u, k1 = (items[begin + 1].ref >> WREF_KIND_SHIFT) & 7u;
+      if (k0 == k1 && (k0 == KIND_TRIANGLE || k0 == KIND_SPHERE)) {
+        out_box = items[begin].box;
+        out_box.grow(items[begin + 1].box);
+        auto& list = k0 == KIND_TRIANGLE ? pairs : sph_pairs;
+        list.emplace_back(items[begin].ref & WREF_INDEX_MASK, items[begin + 1].ref & WREF_INDEX_MASK);
+        return WREF_LEAF | ((k0 == KIND_TRIANGLE ? KIND_TRI_PAIR : KIND_SPH_PAIR) << WREF_KIND_SHIFT) |
+               (uint32_t)(list.size() - 1);
+      }
     }
     const uint32_t idx = (uint32_t)hs.nodes.size();
     hs.nodes.emplace_back();
@@ -317,14 +323,16 @@ void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out, 
   }
 
   L.sph = bl.reserve((size_t)L.n_sph * 4 * RS);
-  L.sph_k = bl.reserve((size_t)L.n_sph * RS);
+  uint32_t n_big = 0;  // the big spheres come first in the sphere array; only they have a K
+  while (n_big < L.n_sph && hs.sph_big[n_big]) n_big++;
+  L.sph_k = bl.reserve((size_t)n_big * RS);
   L.meta_sph = bl.reserve((size_t)L.n_sph * 4);
   for (uint32_t i = 0; i < L.n_sph; ++i) {
     int p = hs.sph[i];
     const double* d = &hs.prim_data[(size_t)p * HT_PRIM_STRIDE];
     for (int a = 0; a < 4; ++a) bl.put<R>(L.sph + (i * 4 + a) * RS, (R)d[a]);
     double K = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] - d[3] * d[3];
-    bl.put<R>(L.sph_k + i * RS, (R)K);
+    if (i < n_big) bl.put<R>(L.sph_k + i * RS, (R)K);
     bl.put<uint32_t>(L.meta_sph + i * 4, ((uint32_t)hs.prim_material[p] << META_MAT_SHIFT) | (uint32_t)p);
   }
 
@@ -358,10 +366,10 @@ void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out, 
     bl.put<uint32_t>(L.meta_tri + i * 4, ((uint32_t)hs.prim_material[p] << META_MAT_SHIFT) | (uint32_t)p);
   }
 
-  L.mat = bl.reserve((size_t)L.n_mat * 4 * RS);
+  L.mat = bl.reserve((size_t)L.n_mat * 2 * RS);
   for (uint32_t i = 0; i < L.n_mat; ++i) {
-    put_bits<R>(bl, L.mat + i * 4 * RS, (uint32_t)hs.mat_type[i] | ((uint32_t)hs.mat_texture[i] << 4));
-    bl.put<R>(L.mat + (i * 4 + 1) * RS, (R)hs.mat_param[i]);
+    put_bits<R>(bl, L.mat + i * 2 * RS, (uint32_t)hs.mat_type[i] | ((uint32_t)hs.mat_texture[i] << 4));
+    bl.put<R>(L.mat + (i * 2 + 1) * RS, (R)hs.mat_param[i]);
   }
 
   L.tex = bl.reserve((size_t)L.n_tex * 4 * RS);
@@ -654,6 +662,7 @@ int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err, co
   }
   hs.nodes.clear();
   hs.depth = 0;
+  std::vector<std::pair<uint32_t, uint32_t>> tri_pairs, sph_pairs;  // leaves of two, from the builder
   if (nb == 1) {
     // like the reference's BVH(only, only) (BVH.scala:30): the same leaf twice
     BvhNode nd;
@@ -676,38 +685,59 @@ int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err, co
     wide_levels = std::min(WIDE_STACK_MAX_DEPTH, std::max(18, wide_levels));
     b.build(0, nb, small ? STACK_MAX_DEPTH : wide_levels, 0, rb);
     hs.depth = b.max_level;
-    if (!b.pairs.empty()) {
-      // the two triangles of a pair must be neighbours in the triangle array: pairs first,
-      // in the order the builder made them, then every other triangle in its old order
-      const size_t nt = hs.tri.size();
-      std::vector<uint32_t> new_index(nt, 0xFFFFFFFFu);
-      std::vector<int32_t> new_tri;
-      new_tri.reserve(nt);
-      std::vector<uint32_t> pair_first(b.pairs.size());
-      for (size_t k = 0; k < b.pairs.size(); ++k) {
-        pair_first[k] = (uint32_t)new_tri.size();
-        for (uint32_t old : {b.pairs[k].first, b.pairs[k].second}) {
-          new_index[old] = (uint32_t)new_tri.size();
-          new_tri.push_back(hs.tri[old]);
+    tri_pairs.swap(b.pairs);
+    sph_pairs.swap(b.sph_pairs);
+  }
+  {
+    // the two primitives of a pair must be neighbours in the array of their kind: flagged
+    // primitives first (the big spheres, never part of a pair), then the pairs in the order
+    // the builder made them, then every other one in its old order
+    auto regroup = [&](const std::vector<std::pair<uint32_t, uint32_t>>& pairs, std::vector<int32_t>& prims,
+                       uint32_t single_kind, uint32_t pair_kind, std::vector<uint8_t>* flags) {
+      if (pairs.empty() && !flags) return;
+      const size_t np = prims.size();
+      std::vector<uint32_t> new_index(np, 0xFFFFFFFFu);
+      std::vector<int32_t> new_prims;
+      new_prims.reserve(np);
+      for (size_t old = 0; flags && old < np; ++old)
+        if ((*flags)[old]) {
+          new_index[old] = (uint32_t)new_prims.size();
+          new_prims.push_back(prims[old]);
+        }
+      std::vector<uint32_t> pair_first(pairs.size());
+      for (size_t k = 0; k < pairs.size(); ++k) {
+        pair_first[k] = (uint32_t)new_prims.size();
+        for (uint32_t old : {pairs[k].first, pairs[k].second}) {
+          new_index[old] = (uint32_t)new_prims.size();
+          new_prims.push_back(prims[old]);
         }
       }
-      for (size_t old = 0; old < nt; ++old)
+      for (size_t old = 0; old < np; ++old)
         if (new_index[old] == 0xFFFFFFFFu) {
-          new_index[old] = (uint32_t)new_tri.size();
-          new_tri.push_back(hs.tri[old]);
+          new_index[old] = (uint32_t)new_prims.size();
+          new_prims.push_back(prims[old]);
         }
-      hs.tri.swap(new_tri);
+      prims.swap(new_prims);
+      if (flags) {
+        std::vector<uint8_t> nf(np);
+        for (size_t old = 0; old < np; ++old) nf[new_index[old]] = (*flags)[old];
+        flags->swap(nf);
+      }
       auto renumber = [&](uint32_t r) -> uint32_t {
         if (!(r & WREF_LEAF) || r == WREF_EMPTY) return r;
         const uint32_t kind = (r >> WREF_KIND_SHIFT) & 7u, i = r & WREF_INDEX_MASK;
-        if (kind == KIND_TRIANGLE) return (r & ~WREF_INDEX_MASK) | new_index[i];
-        if (kind == KIND_TRI_PAIR) return (r & ~WREF_INDEX_MASK) | pair_first[i];
+        // a big sphere shares the sphere array with the ordinary ones
+        if (kind == single_kind || (single_kind == KIND_SPHERE && kind == KIND_BIG_SPHERE))
+          return (r & ~WREF_INDEX_MASK) | new_index[i];
+        if (kind == pair_kind) return (r & ~WREF_INDEX_MASK) | pair_first[i];
         return r;
       };
       for (auto& nd : hs.nodes) { nd.child[0] = renumber(nd.child[0]); nd.child[1] = renumber(nd.child[1]); }
       for (auto& r : hs.hoist) r = renumber(r);
       for (auto& r : hs.prim_ref) r = renumber(r);
-    }
+    };
+    regroup(tri_pairs, hs.tri, KIND_TRIANGLE, KIND_TRI_PAIR, nullptr);
+    regroup(sph_pairs, hs.sph, KIND_SPHERE, KIND_SPH_PAIR, &hs.sph_big);
   }
   for (int a = 0; a < 3; ++a) {
     hs.root_lo[a] = nb ? root.lo[a] : 0.0;

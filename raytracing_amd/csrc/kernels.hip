@@ -440,13 +440,20 @@ __device__ __forceinline__ void triangle_test(const Scene& sc, const Ray<R>& ray
   tv.best_ref = ok ? ref : tv.best_ref;
 }
 // A triangle leaf: triangle idx, and for a pair (KIND_TRI_PAIR) triangle idx + 1 as well.  The
-// hit is recorded under the single triangle's own reference.
+// hit is recorded under the single triangle's own reference.  Sphere leaves likewise.
 template <typename R, bool CNT, bool WIDE>
 __device__ __forceinline__ void triangle_pair_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t idx,
                                                    bool pair, R t_min, Cnt& cnt) {
   const uint32_t single = RefT<WIDE>::LEAF | (KIND_TRIANGLE << RefT<WIDE>::KIND_SHIFT);
   triangle_test<R, CNT>(sc, ray, tv, single | idx, idx, t_min, cnt);
   if (pair) triangle_test<R, CNT>(sc, ray, tv, single | (idx + 1u), idx + 1u, t_min, cnt);
+}
+template <typename R, bool CNT, bool WIDE>
+__device__ __forceinline__ void sphere_pair_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t idx,
+                                                 bool pair, R t_min, Cnt& cnt) {
+  const uint32_t single = RefT<WIDE>::LEAF | (KIND_SPHERE << RefT<WIDE>::KIND_SHIFT);
+  sphere_test<R, CNT>(sc, ray, tv, single | idx, KIND_SPHERE, idx, t_min, cnt);
+  if (pair) sphere_test<R, CNT>(sc, ray, tv, single | (idx + 1u), KIND_SPHERE, idx + 1u, t_min, cnt);
 }
 template <typename R, bool CNT>
 __device__ __forceinline__ void rect_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t ref,
@@ -469,6 +476,7 @@ __device__ __forceinline__ void prim_test(const Scene& sc, const Ray<R>& ray, Tr
   const uint32_t kind = (ref >> RefT<WIDE>::KIND_SHIFT) & 7u, idx = ref & RefT<WIDE>::INDEX_MASK;
   if (kind == KIND_TRIANGLE) triangle_test<R, CNT>(sc, ray, tv, ref, idx, t_min, cnt);
   else if (kind == KIND_TRI_PAIR) triangle_pair_test<R, CNT, WIDE>(sc, ray, tv, idx, true, t_min, cnt);
+  else if (kind == KIND_SPH_PAIR) sphere_pair_test<R, CNT, WIDE>(sc, ray, tv, idx, true, t_min, cnt);
   else if (kind == KIND_SPHERE || kind == KIND_BIG_SPHERE) sphere_test<R, CNT>(sc, ray, tv, ref, kind, idx, t_min, cnt);
   else rect_test<R, CNT>(sc, ray, tv, ref, kind, idx, t_min, cnt);
 }
@@ -481,7 +489,8 @@ __device__ __forceinline__ void leaf_test(const Scene& sc, const Ray<R>& ray, Tr
   const uint32_t idx = ref & RefT<WIDE>::INDEX_MASK;
   if (TRIS || sc.L.tree_kinds == TREE_TRIANGLES)
     triangle_pair_test<R, CNT, WIDE>(sc, ray, tv, idx, ((ref >> RefT<WIDE>::KIND_SHIFT) & 7u) == KIND_TRI_PAIR, t_min, cnt);
-  else if (sc.L.tree_kinds == TREE_SPHERES) sphere_test<R, CNT>(sc, ray, tv, ref, KIND_SPHERE, idx, t_min, cnt);
+  else if (sc.L.tree_kinds == TREE_SPHERES)
+    sphere_pair_test<R, CNT, WIDE>(sc, ray, tv, idx, ((ref >> RefT<WIDE>::KIND_SHIFT) & 7u) == KIND_SPH_PAIR, t_min, cnt);
   else prim_test<R, CNT, WIDE>(sc, ray, tv, ref, t_min, cnt);
 }
 
@@ -819,7 +828,8 @@ __device__ __forceinline__ bool shade_surface(const Scene& sc, const uint32_t* _
                                               const Trav<R>& tv, V3<R>& T, const SinkT& sink,
                                               Surface<R>& sf, Cnt& cnt) {
   HitGeom<R> h = hit_geometry<R, WIDE>(sc, ray, tv.best_t, tv.best_ref);
-  typename M<R>::R4 m = load_r4<R>(sc, sc.L.mat, h.meta >> META_MAT_SHIFT);
+  struct alignas(2 * sizeof(R)) MatRec { R x, y; };  // (type | texture << 4) in the low word, parameter
+  const MatRec m = *(const MatRec*)(sc.base + sc.L.mat + (h.meta >> META_MAT_SHIFT) * (uint32_t)sizeof(MatRec));
   const uint32_t m0 = M<R>::bits_lo(m.x);
   const uint32_t tex = m0 >> 4;
   sf.mkind = m0 & 15u;

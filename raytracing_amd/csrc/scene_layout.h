@@ -64,6 +64,8 @@ enum : uint32_t {
                         // visit fewer than two single leaves under a node of their own.  Only a
                         // node's child is ever a pair; a closest hit is recorded as the single
                         // triangle's reference.
+  KIND_SPH_PAIR = 7,    // the same for two ordinary spheres (index < 0xFFF: kind 7 with all index
+                        // bits set is the empty reference)
 };
 // SceneLayout::tree_kinds.  TREE_SPHERES means ordinary spheres only: a KIND_BIG_SPHERE
 // inside the hierarchy sets TREE_MIXED as well, which sends leaves through the full dispatch.
