@@ -200,3 +200,47 @@ def test_scene_far_from_the_origin(dev, oracle_mod):
     assert np.array_equal(got[0], got[1])                      # the two stores agree in fp32
     assert (got[0] != ofh["prim_id"]).mean() < 0.03            # fp32 coordinates at 6000: silhouettes only
     assert len(np.unique(ofh["prim_id"])) > 50
+
+
+@pytest.mark.parametrize("n_sph,n_tri,n_rect", [(9, 0, 0), (0, 9, 0), (3, 7, 0), (17, 23, 2), (2, 2, 6), (40, 41, 0)])
+def test_leaves_of_two_primitives(dev, oracle_mod, n_sph, n_tri, n_rect):
+    """The hierarchy puts two triangles, or two ordinary spheres, that end up alone under a
+    node into one leaf and renumbers the primitives so that they are neighbours; odd counts,
+    mixed kinds and a big sphere among the small ones must all keep their ids: the closest
+    hit of every pixel is the oracle's (which knows no such leaves), in both stores."""
+    rng = np.random.default_rng(n_sph * 1000 + n_tri * 10 + n_rect)
+    grey = Diffuse(SolidColor((0.7, 0.7, 0.7)))
+    world = [Sphere((0.0, -1000.5, 0.0), 1000.0, grey)]  # hoisted, and first in the sphere array
+    eye = np.array((0.0, 1.0, 12.0))
+    for _ in range(n_sph):
+        world.append(Sphere(tuple(rng.uniform(-3, 3, 3) * (1, 0.5, 1) + (0, 1.5, 0)), float(rng.uniform(0.1, 0.5)), grey))
+    for _ in range(n_tri):
+        a = rng.uniform(-3, 3, 3) * (1, 0.5, 1) + (0, 1.5, 0)
+        b, c = a + rng.uniform(-0.8, 0.8, 3), a + rng.uniform(-0.8, 0.8, 3)
+        if np.dot(np.cross(b - a, c - a), eye - a) < 0:  # triangles are one-sided (Hittable.scala:102): face the camera
+            b, c = c, b
+        world.append(Triangle((tuple(a), tuple(b), tuple(c)), grey))
+    for k in range(n_rect):
+        c = rng.uniform(-2, 2, 3) * (1, 0.5, 1) + (0, 1.5, 0)
+        R = (XYRect, XZRect, YZRect)[k % 3]
+        world.append(R(c[0] - 0.4, c[0] + 0.4, c[1] - 0.3, c[1] + 0.3, float(c[2]), grey))
+    rng.shuffle(world)
+    flat = flatten(world)
+    cam = Camera(tuple(eye), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 35.0, 1.5, 0.0, -1.0, (0.5, 0.7, 1.0))
+    W, H = 150, 100
+    ofh = oracle_mod.OracleScene(flat, bvh_seed=2).first_hit(cam, W, H)
+    assert len(np.unique(ofh["prim_id"])) > (n_sph + n_tri + n_rect) // 2
+    for hbm in (0, 1):
+        dev.set_option("force_hbm_scene", hbm)
+        try:
+            with dev.Scene(flat, device=0) as s:
+                info = s.info()
+                assert 0 < info["n_nodes"] < flat.n_prims - 1  # fewer nodes than one leaf per primitive takes
+                fh = s.first_hit(cam, W, H, precision=A.HT_PRECISION_FP64)
+                g32 = s.first_hit(cam, W, H)
+        finally:
+            dev.set_option("force_hbm_scene", 0)
+        assert np.array_equal(fh["prim_id"], ofh["prim_id"])
+        hit = ofh["prim_id"] >= 0
+        np.testing.assert_allclose(fh["t64"][hit], ofh["t"][hit], rtol=1e-9)
+        assert (g32["prim_id"] == ofh["prim_id"]).mean() > 0.995  # fp32: silhouettes may go either way

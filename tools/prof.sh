@@ -1,6 +1,8 @@
 #!/bin/bash
 # Profiling recipe (run on the GPU box through gpurun): kernel trace + PMC passes.
 #   tools/prof.sh <tag> [workload]      workload: a bench.py --workload name (default dragon)
+# gpurun merges the output into the local gpurun_out/prof: remove that directory before a run
+# with a tag used before, or the summaries add the old result files to the new ones.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -22,7 +22,10 @@ base = os.path.join(ROOT, "gpurun_out", "prof")
 def counter(pass_no, name):
     """Sum over the dispatches of the production render kernel (not the counters build)."""
     tot = collections.defaultdict(float)
-    for f in glob.glob(f"{base}/pmc{pass_no}_{tag}/*/*_counter_collection.csv"):
+    files = glob.glob(f"{base}/pmc{pass_no}_{tag}/*/*_counter_collection.csv")
+    # results of an earlier run with the same tag, merged into the same directory, would be summed in
+    assert len(files) == 1, f"pass {pass_no}: {len(files)} result files under {base}; remove the old ones and profile again"
+    for f in files:
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             if "render_kernel" in k and ", true," not in k and r["Counter_Name"] == name:
