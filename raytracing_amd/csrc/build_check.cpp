@@ -1,0 +1,261 @@
+// build_check.cpp — CPU-only checker of the scene builder (host_scene.cpp): random worlds in,
+// structural invariants of the hierarchy and of the scene image out.  Built with
+// AddressSanitizer + UBSan by `make build_check`; no device code, no HIP runtime.
+//
+//   build_check <n_spheres> <n_triangles> <n_rects> <seed> [force_hbm]
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <random>
+#include <string>
+#include <vector>
+
+#include "host_scene.h"
+
+using namespace ht;
+
+namespace {
+
+struct Box3 {
+  double lo[3], hi[3];
+};
+
+int g_fail = 0;
+#define CHECK(cond, ...)                        \
+  do {                                          \
+    if (!(cond)) {                              \
+      fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__); \
+      fprintf(stderr, __VA_ARGS__);             \
+      fprintf(stderr, "\n");                    \
+      g_fail++;                                 \
+    }                                           \
+  } while (0)
+
+Box3 prim_box(const HostScene& hs, int p) {
+  const double* d = &hs.prim_data[(size_t)p * HT_PRIM_STRIDE];
+  Box3 b;
+  for (int a = 0; a < 3; ++a) { b.lo[a] = 1e300; b.hi[a] = -1e300; }
+  auto grow = [&](const double* q) {
+    for (int a = 0; a < 3; ++a) { b.lo[a] = fmin(b.lo[a], q[a]); b.hi[a] = fmax(b.hi[a], q[a]); }
+  };
+  switch (hs.prim_type[p]) {
+    case HT_PRIM_SPHERE: {
+      double r = fabs(d[3]);
+      double lo[3] = {d[0] - r, d[1] - r, d[2] - r}, hi[3] = {d[0] + r, d[1] + r, d[2] + r};
+      grow(lo); grow(hi);
+      break;
+    }
+    case HT_PRIM_XYRECT: { double lo[3] = {fmin(d[0], d[1]), fmin(d[2], d[3]), d[4]}, hi[3] = {fmax(d[0], d[1]), fmax(d[2], d[3]), d[4]}; grow(lo); grow(hi); break; }
+    case HT_PRIM_XZRECT: { double lo[3] = {fmin(d[0], d[1]), d[4], fmin(d[2], d[3])}, hi[3] = {fmax(d[0], d[1]), d[4], fmax(d[2], d[3])}; grow(lo); grow(hi); break; }
+    case HT_PRIM_YZRECT: { double lo[3] = {d[4], fmin(d[0], d[1]), fmin(d[2], d[3])}, hi[3] = {d[4], fmax(d[0], d[1]), fmax(d[2], d[3])}; grow(lo); grow(hi); break; }
+    default: grow(d); grow(d + 3); grow(d + 6);
+  }
+  return b;
+}
+
+// primitives a leaf reference stands for
+void leaf_prims(const HostScene& hs, uint32_t ref, std::vector<int>& out) {
+  const uint32_t kind = (ref >> WREF_KIND_SHIFT) & 7u, i = ref & WREF_INDEX_MASK;
+  switch (kind) {
+    case KIND_SPHERE: case KIND_BIG_SPHERE:
+      CHECK(i < hs.sph.size(), "sphere index %u of %zu", i, hs.sph.size());
+      if (i < hs.sph.size()) {
+        CHECK((hs.sph_big[i] != 0) == (kind == KIND_BIG_SPHERE), "sphere %u: kind %u against big flag %d", i, kind, hs.sph_big[i]);
+        out.push_back(hs.sph[i]);
+      }
+      break;
+    case KIND_SPH_PAIR:
+      CHECK(i + 1 < hs.sph.size(), "sphere pair %u of %zu", i, hs.sph.size());
+      if (i + 1 < hs.sph.size()) {
+        CHECK(!hs.sph_big[i] && !hs.sph_big[i + 1], "a big sphere inside a pair at %u", i);
+        out.push_back(hs.sph[i]);
+        out.push_back(hs.sph[i + 1]);
+      }
+      break;
+    case KIND_TRIANGLE:
+      CHECK(i < hs.tri.size(), "triangle index %u of %zu", i, hs.tri.size());
+      if (i < hs.tri.size()) out.push_back(hs.tri[i]);
+      break;
+    case KIND_TRI_PAIR:
+      CHECK(i + 1 < hs.tri.size(), "triangle pair %u of %zu", i, hs.tri.size());
+      if (i + 1 < hs.tri.size()) { out.push_back(hs.tri[i]); out.push_back(hs.tri[i + 1]); }
+      break;
+    default:
+      CHECK(i < hs.rect.size(), "rect index %u of %zu", i, hs.rect.size());
+      if (i < hs.rect.size()) {
+        const int p = hs.rect[i];
+        const int want = kind == KIND_XYRECT ? HT_PRIM_XYRECT : (kind == KIND_XZRECT ? HT_PRIM_XZRECT : HT_PRIM_YZRECT);
+        CHECK(hs.prim_type[p] == want, "rect %u: kind %u against primitive type %d", i, kind, hs.prim_type[p]);
+        out.push_back(p);
+      }
+  }
+}
+
+struct Walk {
+  const HostScene& hs;
+  std::vector<int> seen;   // times every primitive was reached
+  std::vector<int> visited;  // nodes
+  int max_level = 0, pairs = 0;
+  // returns the box of everything below `ref`
+  Box3 below(uint32_t ref, int level) {
+    Box3 b;
+    for (int a = 0; a < 3; ++a) { b.lo[a] = 1e300; b.hi[a] = -1e300; }
+    if (ref == WREF_EMPTY) return b;
+    if (ref & WREF_LEAF) {
+      std::vector<int> ps;
+      leaf_prims(hs, ref, ps);
+      if (ps.size() == 2) pairs++;
+      for (int p : ps) {
+        seen[p]++;
+        Box3 q = prim_box(hs, p);
+        for (int a = 0; a < 3; ++a) { b.lo[a] = fmin(b.lo[a], q.lo[a]); b.hi[a] = fmax(b.hi[a], q.hi[a]); }
+      }
+      return b;
+    }
+    CHECK(ref < hs.nodes.size(), "node index %u of %zu", ref, hs.nodes.size());
+    if (ref >= hs.nodes.size()) return b;
+    CHECK(visited[ref] == 0, "node %u reached twice", ref);
+    visited[ref]++;
+    if (level + 1 > max_level) max_level = level + 1;
+    const BvhNode& n = hs.nodes[ref];
+    for (int c = 0; c < 2; ++c) {
+      Box3 q = below(n.child[c], level + 1);
+      for (int a = 0; a < 3; ++a) {
+        if (q.lo[a] <= q.hi[a]) {
+          CHECK(n.lo[c][a] <= q.lo[a] && n.hi[c][a] >= q.hi[a], "node %u child %d axis %d: box [%g, %g] does not hold [%g, %g]",
+                ref, c, a, n.lo[c][a], n.hi[c][a], q.lo[a], q.hi[a]);
+          b.lo[a] = fmin(b.lo[a], q.lo[a]);
+          b.hi[a] = fmax(b.hi[a], q.hi[a]);
+        }
+      }
+    }
+    return b;
+  }
+};
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 5) { fprintf(stderr, "usage: build_check n_spheres n_triangles n_rects seed [force_hbm]\n"); return 2; }
+  const int ns = atoi(argv[1]), nt = atoi(argv[2]), nr = atoi(argv[3]);
+  std::mt19937_64 rng((uint64_t)atoll(argv[4]));
+  const bool force_hbm = argc > 5 && atoi(argv[5]) != 0;
+  std::uniform_real_distribution<double> U(-1.0, 1.0);
+
+  std::vector<int32_t> type, mat;
+  std::vector<double> data;
+  auto add = [&](int t, std::initializer_list<double> v) {
+    type.push_back(t);
+    mat.push_back((int32_t)(type.size() % 3));
+    size_t o = data.size();
+    data.resize(o + HT_PRIM_STRIDE, 0.0);
+    size_t k = 0;
+    for (double x : v) data[o + k++] = x;
+  };
+  const double spread = 4.0 + cbrt((double)(ns + nt + nr));
+  for (int i = 0; i < ns; ++i) {
+    if (i == ns / 2) { add(HT_PRIM_SPHERE, {0.0, -1000.0 - spread, 0.0, 1000.0}); continue; }  // a ground sphere among the rest
+    add(HT_PRIM_SPHERE, {U(rng) * spread, U(rng) * spread, U(rng) * spread, 0.05 + 0.3 * fabs(U(rng))});
+  }
+  for (int i = 0; i < nt; ++i) {
+    double a[3] = {U(rng) * spread, U(rng) * spread, U(rng) * spread};
+    add(HT_PRIM_TRIANGLE, {a[0], a[1], a[2], a[0] + U(rng), a[1] + U(rng), a[2] + U(rng), a[0] + U(rng), a[1] + U(rng), a[2] + U(rng)});
+  }
+  for (int i = 0; i < nr; ++i) {
+    double c[3] = {U(rng) * spread, U(rng) * spread, U(rng) * spread};
+    add(HT_PRIM_XYRECT + i % 3, {c[0] - 0.3, c[0] + 0.3, c[1] - 0.2, c[1] + 0.2, c[2]});
+  }
+  // shuffle the world order: kinds interleaved as a scene file would have them
+  const int n = (int)type.size();
+  for (int i = n - 1; i > 0; --i) {
+    int j = (int)(rng() % (uint64_t)(i + 1));
+    std::swap(type[i], type[j]);
+    std::swap(mat[i], mat[j]);
+    for (int k = 0; k < HT_PRIM_STRIDE; ++k) std::swap(data[(size_t)i * HT_PRIM_STRIDE + k], data[(size_t)j * HT_PRIM_STRIDE + k]);
+  }
+  std::vector<int32_t> group(n);
+  for (int i = 0; i < n; ++i) group[i] = i;
+  int32_t mat_type[3] = {HT_MAT_DIFFUSE, HT_MAT_GLASS, HT_MAT_EMISSION}, mat_tex[3] = {0, 0, 0};
+  double mat_param[3] = {0.0, 1.5, 2.0};
+  int32_t tex_type[1] = {HT_TEX_SOLID}, tex_child[2] = {0, 0};
+  double tex_data[HT_TEX_STRIDE] = {0.5, 0.5, 0.5};
+
+  ht_scene_desc d;
+  memset(&d, 0, sizeof d);
+  d.n_prims = n;
+  d.prim_type = type.data();
+  d.prim_material = mat.data();
+  d.prim_data = data.data();
+  d.prim_group = group.data();
+  d.n_materials = 3;
+  d.mat_type = mat_type;
+  d.mat_texture = mat_tex;
+  d.mat_param = mat_param;
+  d.n_textures = 1;
+  d.tex_type = tex_type;
+  d.tex_data = tex_data;
+  d.tex_child = tex_child;
+
+  HostScene hs;
+  std::string err;
+  BuildOptions opt;
+  opt.force_hbm = force_hbm;
+  int rc = build_host_scene(&d, hs, err, opt);
+  if (rc != HT_OK) { fprintf(stderr, "build failed: %d %s\n", rc, err.c_str()); return 1; }
+
+  // the per-kind arrays are a partition of the primitives, and prim_ref finds each one again
+  CHECK((int)(hs.sph.size() + hs.rect.size() + hs.tri.size()) == n, "per-kind arrays hold %zu primitives of %d", hs.sph.size() + hs.rect.size() + hs.tri.size(), n);
+  CHECK(hs.sph_big.size() == hs.sph.size(), "big flags");
+  bool small_seen = false;
+  for (size_t i = 0; i < hs.sph.size(); ++i) {
+    if (!hs.sph_big[i]) small_seen = true;
+    else CHECK(!small_seen, "big sphere %zu after an ordinary one", i);
+  }
+  for (int p = 0; p < n; ++p) {
+    std::vector<int> ps;
+    const uint32_t kind = (hs.prim_ref[p] >> WREF_KIND_SHIFT) & 7u;
+    CHECK(kind != KIND_TRI_PAIR && kind != KIND_SPH_PAIR, "primitive %d is referenced as a pair", p);
+    leaf_prims(hs, hs.prim_ref[p], ps);
+    CHECK(ps.size() == 1 && ps[0] == p, "prim_ref of %d leads to %d", p, ps.empty() ? -1 : ps[0]);
+  }
+  // every primitive is reached once: through the hoist list or through the hierarchy
+  Walk w{hs, std::vector<int>(n, 0), std::vector<int>(hs.nodes.size(), 0)};
+  for (uint32_t r : hs.hoist) {
+    std::vector<int> ps;
+    leaf_prims(hs, r, ps);
+    CHECK(ps.size() == 1, "a pair in the hoist list");
+    for (int p : ps) w.seen[p]++;
+  }
+  const bool twin = hs.nodes.size() == 1 && hs.nodes[0].child[0] == hs.nodes[0].child[1];  // BVH(only, only)
+  if (!hs.nodes.empty()) {
+    Box3 all = w.below(0u, 0);
+    for (int a = 0; a < 3; ++a)
+      CHECK(hs.root_lo[a] <= all.lo[a] && hs.root_hi[a] >= all.hi[a], "root box axis %d", a);
+  }
+  for (int p = 0; p < n; ++p) CHECK(w.seen[p] == ((twin && w.seen[p] == 2) ? 2 : 1), "primitive %d reached %d times", p, w.seen[p]);
+  for (size_t i = 0; i < hs.nodes.size(); ++i) CHECK(w.visited[i] == 1, "node %zu reached %d times", i, w.visited[i]);
+  CHECK(w.max_level == hs.depth, "depth %d, walked %d", hs.depth, w.max_level);
+  // the scene images
+  for (const SceneLayout* L : {&hs.layout32, &hs.layout64}) {
+    const std::vector<uint8_t>& blob = L == &hs.layout32 ? hs.blob32 : hs.blob64;
+    CHECK(L->total_bytes == blob.size() && blob.size() % 16 == 0, "image size");
+    CHECK(L->n_nodes == hs.nodes.size() && L->depth == (uint32_t)hs.depth, "layout counts");
+    CHECK(!force_hbm || L->wide, "forced HBM store not taken");
+    if (!L->wide) {
+      CHECK(hs.depth <= STACK_MAX_DEPTH && hs.sph.size() <= MAX_PER_KIND && hs.tri.size() <= MAX_PER_KIND, "on-chip limits");
+      const uint32_t stride = L == &hs.layout32 ? 64u : 112u, co = L == &hs.layout32 ? 48u : 96u;
+      for (size_t i = 0; i < hs.nodes.size(); ++i) {
+        uint32_t cc;
+        memcpy(&cc, blob.data() + L->nodes + i * stride + co, 4);
+        CHECK((cc & 0xFFFFu) == narrow_ref(hs.nodes[i].child[0]) && (cc >> 16) == narrow_ref(hs.nodes[i].child[1]), "node %zu: children in the image", i);
+        CHECK((cc & 0xFFFFu) != REF_EMPTY && (cc >> 16) != REF_EMPTY, "node %zu: a child reads as the empty reference", i);
+      }
+    }
+  }
+  if (g_fail) { fprintf(stderr, "%d check(s) failed\n", g_fail); return 1; }
+  printf("ok prims=%d nodes=%zu depth=%d pairs=%d hoisted=%zu wide32=%u wide64=%u image32=%u\n", n, hs.nodes.size(), hs.depth,
+         w.pairs, hs.hoist.size(), hs.layout32.wide, hs.layout64.wide, hs.layout32.total_bytes);
+  return 0;
+}

@@ -107,13 +107,13 @@ constexpr uint32_t node_stride(bool wide) {
 struct SceneLayout {
   uint32_t nodes;       // n_nodes * node_stride
   uint32_t sph;         // n_sph   * 4R   {cx, cy, cz, r}
-  uint32_t sph_k;       // n_sph   * R    K (KIND_BIG_SPHERE only)
+  uint32_t sph_k;       // n_big   * R    K of the KIND_BIG_SPHERE entries, which come first in sph
   uint32_t rect;        // n_rect  * 8R   {a0, a1, b0, b1, k, -, -, -}
   uint32_t tri;         // n_tri   * 12R  {A, e1 = B-A, e2 = C-A, n = e1 x e2}
   uint32_t meta_sph;    // n_sph   * u32
   uint32_t meta_rect;   // n_rect  * u32
   uint32_t meta_tri;    // n_tri   * u32
-  uint32_t mat;         // n_mat   * 4R
+  uint32_t mat;         // n_mat   * 2R   {type | texture << 4 (low 32 bits), parameter}
   uint32_t tex;         // n_tex   * 4R
   uint32_t perlin;      // n_perlin * perlin_stride: 256 * 4R gradients, then 3*256 bytes perm
   uint32_t perlin_stride;
