@@ -13,7 +13,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <limits>
+#include <stdexcept>
 
 namespace ht {
 
@@ -83,9 +86,23 @@ Box prim_box(int kind, const double* d) {
   return b;
 }
 
+// A subtree of a large hierarchy that is built on its own, into its own node array, so that
+// several can be built at once; the parent's child slot holds JOB_REF | index until the parts
+// are put together.  Which ranges become jobs depends on the scene alone, never on the
+// number of threads, so the hierarchy (and its numbering) is the same on every machine.
+constexpr uint32_t JOB_REF = 0x7F000000u;
+constexpr int JOB_MIN_SCENE = 65536;  // scenes below this are built in one piece
+constexpr int JOB_MAX_ITEMS = 16384;  // a range of at most this many primitives becomes a job
+struct BuildJob {
+  int begin, end, levels_left, level;
+};
+
 struct Builder {
-  HostScene& hs;
+  BvhNode* nodes;        // room for one node less than the builder has primitives
   std::vector<Item>& items;
+  uint32_t n_nodes = 0;
+  std::vector<BuildJob>* jobs = nullptr;  // non-null: ranges of at most JOB_MAX_ITEMS are deferred
+  std::vector<Item> scratch;
   int max_level = 0;
   // leaves of two triangles / two ordinary spheres: (kind-local index of the first, of the
   // second); a pair's reference carries its position in the list of its kind until the
@@ -115,8 +132,14 @@ struct Builder {
                (uint32_t)(list.size() - 1);
       }
     }
-    const uint32_t idx = (uint32_t)hs.nodes.size();
-    hs.nodes.emplace_back();
+    if (jobs && n <= JOB_MAX_ITEMS) {
+      out_box = items[begin].box;
+      for (int i = begin + 1; i < end; ++i) out_box.grow(items[i].box);
+      jobs->push_back(BuildJob{begin, end, levels_left, level});
+      return JOB_REF | (uint32_t)(jobs->size() - 1);
+    }
+    const uint32_t idx = n_nodes++;
+    nodes[idx] = BvhNode();
     max_level = std::max(max_level, level + 1);
 
     Box cb;
@@ -165,11 +188,18 @@ struct Builder {
       const double scale = NBINS / ext;
       const double lo = cb.lo[best_axis];
       const int ax = best_axis, sp = best_split;
-      auto it = std::stable_partition(items.begin() + begin, items.begin() + end, [&](const Item& it2) {
-        int k = std::min(NBINS - 1, std::max(0, (int)((it2.c[ax] - lo) * scale)));
-        return k <= sp;
-      });
-      mid = (int)(it - items.begin());
+      // a stable partition through the builder's own scratch array (std::stable_partition
+      // takes a temporary buffer from the allocator on every call; with several builders
+      // at work those calls serialise on the process's memory map)
+      scratch.clear();
+      int j = begin;
+      for (int i = begin; i < end; ++i) {
+        const int k = std::min(NBINS - 1, std::max(0, (int)((items[i].c[ax] - lo) * scale)));
+        if (k <= sp) items[j++] = items[i];
+        else scratch.push_back(items[i]);
+      }
+      std::copy(scratch.begin(), scratch.end(), items.begin() + j);
+      mid = j;
     }
     // the traversal stack is bounded: a side must still fit in the levels left
     const int cap = (levels_left - 1 >= 30) ? (1 << 30) : (1 << std::max(0, levels_left - 1));
@@ -184,7 +214,7 @@ struct Builder {
     Box lb, rb;
     uint32_t l = build(begin, mid, levels_left - 1, level + 1, lb);
     uint32_t r = build(mid, end, levels_left - 1, level + 1, rb);
-    BvhNode& nd = hs.nodes[idx];
+    BvhNode& nd = nodes[idx];
     for (int a = 0; a < 3; ++a) {
       nd.lo[0][a] = lb.lo[a]; nd.hi[0][a] = lb.hi[a];
       nd.lo[1][a] = rb.lo[a]; nd.hi[1][a] = rb.hi[a];
@@ -217,28 +247,68 @@ template <> float round_up<float>(double d) {
 // Halves are ordered like the signed integer key = +-(bits & 0x7FFF); a binary search
 // over the keys finds the nearest half on the wanted side of d.
 double half_value(int key) {
-  const int m = key < 0 ? -key : key;  // 0 .. 0x7C00 (infinity)
-  const int e = m >> 10, f = m & 0x3FF;
-  double v = e == 0 ? ldexp((double)f, -24) : (e == 31 ? INFINITY : ldexp((double)(f | 0x400), e - 25));
-  return key < 0 ? -v : v;
+  // every non-negative half, tabulated once (31 745 doubles)
+  static const std::vector<double> table = [] {
+    std::vector<double> t(0x7C01);
+    for (int m = 0; m <= 0x7C00; ++m) {
+      const int e = m >> 10, f = m & 0x3FF;
+      t[m] = e == 0 ? ldexp((double)f, -24) : (e == 31 ? INFINITY : ldexp((double)(f | 0x400), e - 25));
+    }
+    return t;
+  }();
+  return key < 0 ? -table[-key] : table[key];
 }
 double half_value_of(uint16_t bits) { return half_value((bits & 0x8000) ? -(int)(bits & 0x7FFF) : (int)bits); }
 uint16_t half_bits(int key) { return key < 0 ? (uint16_t)(0x8000 | -key) : (uint16_t)key; }
-uint16_t half_round_down(double d) {  // largest half <= d
-  int lo = -0x7C00, hi = 0x7C00;      // half_value(lo) = -inf <= d always
-  while (lo < hi) {
-    int mid = lo + (hi - lo + 1) / 2;
-    if (half_value(mid) <= d) lo = mid; else hi = mid - 1;
+// A half at or just inside |d| toward zero, from the binary exponent; the two functions
+// below step from it to the exact neighbour (one or two comparisons instead of a search
+// over all 63 489 keys: the image of a million-triangle mesh rounds fourteen million numbers).
+int half_key_toward_zero(double d) {
+  const double a = fabs(d);
+  int key;
+  if (!(a >= ldexp(1.0, -24))) {
+    key = 0;
+  } else if (a >= 65504.0) {
+    key = a == INFINITY ? 0x7C00 : 0x7BFF;
+  } else {
+    int ex;
+    const double fr = frexp(a, &ex);  // a = fr * 2^ex, fr in [0.5, 1)
+    const int e = ex - 1;
+    if (e < -14) key = (int)floor(ldexp(a, 24));  // subnormal halves: multiples of 2^-24
+    else key = ((e + 15) << 10) | (int)floor((2.0 * fr - 1.0) * 1024.0);
   }
-  return half_bits(lo);
+  return d < 0 ? -key : key;
+}
+uint16_t half_round_down(double d) {  // largest half <= d
+  int key = half_key_toward_zero(d);
+  while (key > -0x7C00 && half_value(key) > d) key--;
+  while (key < 0x7C00 && half_value(key + 1) <= d) key++;
+  return half_bits(key);
 }
 uint16_t half_round_up(double d) {    // smallest half >= d
-  int lo = -0x7C00, hi = 0x7C00;      // half_value(hi) = +inf >= d always
-  while (lo < hi) {
-    int mid = lo + (hi - lo) / 2;
-    if (half_value(mid) >= d) hi = mid; else lo = mid + 1;
+  int key = half_key_toward_zero(d);
+  while (key < 0x7C00 && half_value(key) < d) key++;
+  while (key > -0x7C00 && half_value(key - 1) >= d) key--;
+  return half_bits(key);
+}
+
+// fn(begin, end) over [0, n) on several threads when the range is worth it; every call
+// writes its own part of the image
+template <typename F>
+void parallel_ranges(uint32_t n, F fn) {
+  const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (n < 65536u || hw == 1) { fn(0u, n); return; }
+  std::vector<std::thread> pool;
+  std::atomic<bool> failed{false};  // an exception must not leave a thread: it is thrown again here
+  const uint32_t per = (n + hw - 1) / hw;
+  for (unsigned t = 0; t < hw; ++t) {
+    const uint32_t b = std::min(n, t * per), e = std::min(n, b + per);
+    if (b >= e) continue;
+    auto part = [=, &failed] { try { fn(b, e); } catch (...) { failed = true; } };
+    try { pool.emplace_back(part); } catch (...) { part(); }  // no thread to be had: here, then
   }
-  return half_bits(lo);
+  for (auto& th : pool) th.join();
+  if (failed) throw std::runtime_error("writing the scene image failed");
 }
 
 struct Blob {
@@ -277,7 +347,8 @@ void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out, 
 
   const uint32_t ns = node_stride<R>(wide);
   L.nodes = bl.reserve((size_t)L.n_nodes * ns);
-  for (uint32_t i = 0; i < L.n_nodes; ++i) {
+  parallel_ranges(L.n_nodes, [&](uint32_t i0, uint32_t i1) {
+  for (uint32_t i = i0; i < i1; ++i) {
     const BvhNode& n = hs.nodes[i];
     uint32_t o = L.nodes + i * ns;
     uint32_t co;  // offset of the child references
@@ -321,6 +392,7 @@ void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out, 
       bl.put<uint32_t>(co, narrow_ref(n.child[0]) | (narrow_ref(n.child[1]) << 16));
     }
   }
+  });
 
   L.sph = bl.reserve((size_t)L.n_sph * 4 * RS);
   uint32_t n_big = 0;  // the big spheres come first in the sphere array; only they have a K
@@ -347,7 +419,8 @@ void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out, 
 
   L.tri = bl.reserve((size_t)L.n_tri * 12 * RS);
   L.meta_tri = bl.reserve((size_t)L.n_tri * 4);
-  for (uint32_t i = 0; i < L.n_tri; ++i) {
+  parallel_ranges(L.n_tri, [&](uint32_t i0, uint32_t i1) {
+  for (uint32_t i = i0; i < i1; ++i) {
     int p = hs.tri[i];
     const double* d = &hs.prim_data[(size_t)p * HT_PRIM_STRIDE];
     // edges and normal in fp64 (Hittable.scala:98-100), rounded once
@@ -365,6 +438,7 @@ void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out, 
     }
     bl.put<uint32_t>(L.meta_tri + i * 4, ((uint32_t)hs.prim_material[p] << META_MAT_SHIFT) | (uint32_t)p);
   }
+  });
 
   L.mat = bl.reserve((size_t)L.n_mat * 2 * RS);
   for (uint32_t i = 0; i < L.n_mat; ++i) {
@@ -672,7 +746,6 @@ int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err, co
     hs.nodes.push_back(nd);
     hs.depth = 1;
   } else if (nb > 1) {
-    Builder b{hs, items};
     Box rb;
     // a hierarchy that can live on chip gets the on-chip depth bound; a larger one
     // gets the deeper bound of the HBM store
@@ -683,10 +756,91 @@ int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err, co
     int wide_levels = 1;
     while ((1 << std::min(wide_levels - 1, 30)) < nb && wide_levels < WIDE_STACK_MAX_DEPTH) wide_levels++;
     wide_levels = std::min(WIDE_STACK_MAX_DEPTH, std::max(18, wide_levels));
-    b.build(0, nb, small ? STACK_MAX_DEPTH : wide_levels, 0, rb);
-    hs.depth = b.max_level;
-    tri_pairs.swap(b.pairs);
-    sph_pairs.swap(b.sph_pairs);
+    // A large scene: the top of the hierarchy here, the subtrees of up to JOB_MAX_ITEMS
+    // primitives on several threads, each into its own arrays, appended in job order.
+    std::vector<BuildJob> jobs;
+    hs.nodes.resize((size_t)nb);  // a hierarchy over nb primitives has at most nb - 1 nodes
+    Builder top{hs.nodes.data(), items};
+    if (nb >= JOB_MIN_SCENE) top.jobs = &jobs;
+    top.build(0, nb, small ? STACK_MAX_DEPTH : wide_levels, 0, rb);
+    hs.depth = top.max_level;
+    tri_pairs.swap(top.pairs);
+    sph_pairs.swap(top.sph_pairs);
+    uint32_t n_nodes = top.n_nodes;
+    if (!jobs.empty()) {
+      // every job writes its nodes into a slice of the one array (no allocation inside the
+      // threads: large allocations serialise on the process's memory map); the slices are
+      // closed up afterwards
+      struct Part {
+        uint32_t slice = 0, n_nodes = 0, root = 0;
+        int max_level = 0;
+        std::vector<std::pair<uint32_t, uint32_t>> pairs, sph_pairs;
+      };
+      std::vector<Part> parts(jobs.size());
+      uint32_t slice = top.n_nodes;
+      for (size_t j = 0; j < jobs.size(); ++j) {
+        parts[j].slice = slice;
+        slice += (uint32_t)(jobs[j].end - jobs[j].begin) - 1u;
+      }
+      std::atomic<size_t> next{0};
+      std::atomic<bool> failed{false};  // an exception (out of memory) must not leave a thread
+      auto worker = [&] {
+        try {
+        std::vector<Item> scratch;  // kept from job to job
+        for (size_t j; (j = next.fetch_add(1)) < jobs.size();) {
+          Builder b{hs.nodes.data() + parts[j].slice, items};  // the ranges of different jobs do not overlap
+          b.scratch.swap(scratch);
+          Box box;
+          const uint32_t root = b.build(jobs[j].begin, jobs[j].end, jobs[j].levels_left, jobs[j].level, box);
+          Part done;
+          done.slice = parts[j].slice;
+          done.n_nodes = b.n_nodes;
+          done.root = root;
+          done.max_level = b.max_level;
+          done.pairs.swap(b.pairs);
+          done.sph_pairs.swap(b.sph_pairs);
+          parts[j] = std::move(done);
+          scratch.swap(b.scratch);
+        }
+        } catch (...) { failed = true; }
+      };
+      const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+      std::vector<std::thread> pool;
+      for (unsigned t = 1; t < hw; ++t) {
+        try { pool.emplace_back(worker); } catch (...) { break; }  // fewer threads, same jobs
+      }
+      worker();
+      for (auto& th : pool) th.join();
+      if (failed) throw std::runtime_error("building the hierarchy failed");
+      std::vector<uint32_t> job_root(jobs.size());
+      for (size_t j = 0; j < jobs.size(); ++j) {
+        const uint32_t node0 = n_nodes, tri0 = (uint32_t)tri_pairs.size(), sph0 = (uint32_t)sph_pairs.size();
+        auto moved = [&](uint32_t r) -> uint32_t {  // a reference of the part in the whole hierarchy
+          if (!(r & WREF_LEAF)) return r + node0;
+          const uint32_t kind = (r >> WREF_KIND_SHIFT) & 7u;
+          if (kind == KIND_TRI_PAIR) return r + tri0;
+          if (kind == KIND_SPH_PAIR) return r + sph0;
+          return r;
+        };
+        for (uint32_t k = 0; k < parts[j].n_nodes; ++k) {  // node0 + k <= slice + k: moving down, in order
+          BvhNode nd = hs.nodes[parts[j].slice + k];
+          nd.child[0] = moved(nd.child[0]);
+          nd.child[1] = moved(nd.child[1]);
+          hs.nodes[node0 + k] = nd;
+        }
+        n_nodes += parts[j].n_nodes;
+        tri_pairs.insert(tri_pairs.end(), parts[j].pairs.begin(), parts[j].pairs.end());
+        sph_pairs.insert(sph_pairs.end(), parts[j].sph_pairs.begin(), parts[j].sph_pairs.end());
+        job_root[j] = moved(parts[j].root);
+        hs.depth = std::max(hs.depth, parts[j].max_level);
+      }
+      for (uint32_t i = 0; i < n_nodes; ++i)
+        for (int c = 0; c < 2; ++c) {
+          uint32_t& r = hs.nodes[i].child[c];
+          if (!(r & WREF_LEAF) && r >= JOB_REF) r = job_root[r - JOB_REF];
+        }
+    }
+    hs.nodes.resize(n_nodes);
   }
   {
     // the two primitives of a pair must be neighbours in the array of their kind: flagged
@@ -749,12 +903,26 @@ int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err, co
   }
   const bool chip_ok = fits_refs16 && hs.nodes.size() <= MAX_NODES && hs.depth <= STACK_MAX_DEPTH && !opt.force_hbm;
   const uint32_t beside = lds_beside_image((uint32_t)hs.depth);
-  write_blob<float>(hs, hs.layout32, hs.blob32, !chip_ok);
-  if (chip_ok && (uint64_t)hs.layout32.total_bytes + beside > opt.lds_bytes)
-    write_blob<float>(hs, hs.layout32, hs.blob32, true);
-  write_blob<double>(hs, hs.layout64, hs.blob64, !chip_ok);
-  if (chip_ok && (uint64_t)hs.layout64.total_bytes + beside > opt.lds_bytes)
-    write_blob<double>(hs, hs.layout64, hs.blob64, true);
+  auto image32 = [&] {
+    write_blob<float>(hs, hs.layout32, hs.blob32, !chip_ok);
+    if (chip_ok && (uint64_t)hs.layout32.total_bytes + beside > opt.lds_bytes)
+      write_blob<float>(hs, hs.layout32, hs.blob32, true);
+  };
+  auto image64 = [&] {
+    write_blob<double>(hs, hs.layout64, hs.blob64, !chip_ok);
+    if (chip_ok && (uint64_t)hs.layout64.total_bytes + beside > opt.lds_bytes)
+      write_blob<double>(hs, hs.layout64, hs.blob64, true);
+  };
+  if (n >= JOB_MIN_SCENE) {  // the two images of a large scene side by side
+    std::atomic<bool> failed{false};
+    std::thread other([&] { try { image64(); } catch (...) { failed = true; } });
+    try { image32(); } catch (...) { failed = true; }
+    other.join();
+    if (failed) throw std::runtime_error("writing the scene images failed");
+  } else {
+    image32();
+    image64();
+  }
   if (hs.blob32.size() > 0xFFFFFFF0ull || hs.blob64.size() > 0xFFFFFFF0ull) {
     err = "scene image exceeds 4 GiB";
     return HT_E_TOO_LARGE;
