@@ -324,8 +324,9 @@ int ht_scene_get_info(const ht_scene* scene, ht_scene_info* out);
  *   "wait_threshold"    lanes of a wave that may wait for shading before
  *                       traversal yields (1..64)
  *   "max_blocks_per_cu" cap on resident workgroups per compute unit
- *   "max_waves_per_cu"  cap on resident waves per compute unit (4..32, default 28: what the
- *                       kernels' scalar registers admit; the occupancy query answers more)
+ *   "max_waves_per_cu"  cap on resident waves per compute unit (4..32; 0, the default: what the
+ *                       kernel variant's scalar registers admit, 28 or 32; the occupancy query
+ *                       answers 32 for all)
  *   "block_threads"     force the workgroup size (multiple of 128; 0 = choose for occupancy)
  *   "node_den"          node steps continue while inner-node lanes * node_den >= travelling lanes
  *   "wait_ratio_num" / "wait_ratio_den"  traversal also yields to shading when

@@ -27,6 +27,7 @@ using namespace ht;
 struct LaunchShape {
   int threads = 0, bpc = 0;
   uint32_t lds = 0;
+  uint32_t kfeat = 0;   // the kernel variant the shape is for
   int generation = -1;  // option generation it was worked out under
 };
 
@@ -102,7 +103,7 @@ int fail(int code, const char* fmt, ...) {
 // tuning knobs (ht_set_option)
 std::atomic<int> g_wait_threshold{40};
 std::atomic<int> g_max_blocks_per_cu{8};
-std::atomic<int> g_max_waves_per_cu{28};
+std::atomic<int> g_max_waves_per_cu{0};  // 0: what the kernel variant admits
 std::atomic<int> g_block_threads{0};  // 0: choose
 std::atomic<int> g_node_den{2}, g_wait_num{1000}, g_wait_den{1};
 std::atomic<int> g_default_batch{1024};
@@ -180,24 +181,32 @@ int launch_shape(ht_scene* s, int prec, bool counters, LaunchShape& out) {
   const int gen = g_shape_generation.load();
   if (c.generation != gen) {
     const SceneLayout& L = prec == HT_PRECISION_FP32 ? s->hs.layout32 : s->hs.layout64;
-    const uint32_t kfeat = s->feat | (L.tree_kinds == TREE_TRIANGLES ? KFEAT_TRIS : 0u);
+    const uint32_t base_feat = s->feat | (L.tree_kinds == TREE_TRIANGLES ? KFEAT_TRIS : 0u);
     LaunchShape best;
     const int forced = g_block_threads.load();
-    for (int t = 256; t <= (int)max_block_threads(prec); t += 128) {
-      if (forced > 0 && t != forced) continue;
-      const uint32_t need = lds_bytes_needed(L, (uint32_t)t);
-      int b = render_blocks_per_cu(prec, counters, kfeat, L.wide != 0u, t, need);
-      b = std::min(b, g_max_blocks_per_cu.load());
-      // several workgroups share a CU well only when each fills the four SIMDs evenly: two
-      // groups of 14 waves (measured on the Cornell box) ran 20 % slower than two of 12
-      if (b > 1 && t % 256 != 0) b = 1;
-      // The render kernels use 95 to 105 scalar registers, and a SIMD admits at most seven
-      // waves of a kernel that uses 81 to 96 (fewer beyond; the occupancy API does not know and
-      // answers eight): a second 1024-thread workgroup that the API promises never becomes
-      // resident (measured on the dragon: "1024 x 2" 20.1, 768 x 2 24.3 G samples/s).
-      const int max_waves = g_max_waves_per_cu.load();
-      if (b * t > max_waves * 64) b = max_waves * 64 / t;
-      if (b * t > best.bpc * best.threads) { best.threads = t; best.bpc = b; best.lds = need; }
+    // The variant held to 72 scalar registers runs 2-3 % slower at equal occupancy (it keeps
+    // some scalars in vector lanes) and is the only one a CU holds 32 waves of: it is taken
+    // when that buys a larger shape (dragon: 1024 x 2 instead of 768 x 2, +5 %; Cornell box:
+    // 256 x 8 instead of 256 x 7, +6 %), not otherwise (random.json: 768 x 2 either way).
+    for (int lean = 0; lean <= (render_has_lean_variant(prec, counters, base_feat, L.wide != 0u) ? 1 : 0); ++lean) {
+      const uint32_t kfeat = base_feat | (lean ? KFEAT_LEAN : 0u);
+      for (int t = 256; t <= (int)max_block_threads(prec); t += 128) {
+        if (forced > 0 && t != forced) continue;
+        const uint32_t need = lds_bytes_needed(L, (uint32_t)t);
+        int b = render_blocks_per_cu(prec, counters, kfeat, L.wide != 0u, t, need);
+        b = std::min(b, g_max_blocks_per_cu.load());
+        // several workgroups share a CU well only when each fills the four SIMDs evenly: two
+        // groups of 14 waves (measured on the Cornell box) ran 20 % slower than two of 12
+        if (b > 1 && t % 256 != 0) b = 1;
+        // Most render kernels use 96 to 106 scalar registers, and a SIMD admits at most seven
+        // waves of a kernel that uses more than 80 (the occupancy API does not know and answers
+        // eight): a workgroup promised beyond 28 waves per CU never becomes resident (measured
+        // on the dragon: "1024 x 2" of the 96-register kernel 20.1, 768 x 2 24.3 G samples/s).
+        const int forced_waves = g_max_waves_per_cu.load();
+        const int max_waves = forced_waves > 0 ? forced_waves : render_max_waves_per_cu(prec, counters, kfeat, L.wide != 0u);
+        if (b * t > max_waves * 64) b = max_waves * 64 / t;
+        if (b * t > best.bpc * best.threads) { best.threads = t; best.bpc = b; best.lds = need; best.kfeat = kfeat; }
+      }
     }
     best.generation = gen;
     c = best;
@@ -231,7 +240,7 @@ int make_plan(ht_scene* s, const ht_camera* cam, const ht_render_params* p, int6
   int rc = launch_shape(s, pl.prec, pl.counters, pl.shape);
   if (rc != HT_OK) return rc;
   const SceneLayout& L = pl.prec == HT_PRECISION_FP32 ? s->hs.layout32 : s->hs.layout64;
-  pl.kfeat = s->feat | (L.tree_kinds == TREE_TRIANGLES ? KFEAT_TRIS : 0u);
+  pl.kfeat = pl.shape.kfeat;
   pl.grid = pl.shape.bpc * s->n_cu;
 
   CameraBasis basis;
@@ -514,7 +523,7 @@ const char* ht_last_error(void) { return g_error; }
 int ht_set_option(const char* name, int value) {
   if (!name) return fail(HT_E_INVALID, "option name is NULL");
   if (!strcmp(name, "wait_threshold")) { g_wait_threshold = std::min(64, std::max(1, value)); return HT_OK; }
-  if (!strcmp(name, "max_waves_per_cu")) { g_max_waves_per_cu = std::min(32, std::max(4, value)); g_shape_generation++; return HT_OK; }
+  if (!strcmp(name, "max_waves_per_cu")) { g_max_waves_per_cu = value <= 0 ? 0 : std::min(32, std::max(4, value)); g_shape_generation++; return HT_OK; }
   if (!strcmp(name, "max_blocks_per_cu")) { g_max_blocks_per_cu = std::max(1, value); g_shape_generation++; return HT_OK; }
   if (!strcmp(name, "default_batch")) { g_default_batch = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "chunk")) { g_chunk = std::max(0, value); return HT_OK; }

@@ -991,8 +991,7 @@ template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
 struct MinWaves { static constexpr int value = (sizeof(R) == 4 && !CNT) ? ((FEAT & 3u) == 0u ? 6 : ((FEAT & 3u) == 3u ? 4 : 5)) : 1; };
 
 template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
-__global__ void __launch_bounds__(M<R>::BT) __attribute__((amdgpu_waves_per_eu(MinWaves<R, CNT, FEAT, WIDE>::value)))
-render_kernel(RenderArgs A, CamDev<R> cam) {
+__device__ __forceinline__ void render_body(const RenderArgs& A) {
   extern __shared__ __align__(16) uint8_t lds[];
   typedef RefT<WIDE> RF;
   typedef typename RF::stack_t stack_t;
@@ -1261,6 +1260,28 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
       if (lane == 0) atomicAdd(&A.counters[k], tot);
     }
   }
+}
+
+template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
+__global__ void __launch_bounds__(M<R>::BT) __attribute__((amdgpu_waves_per_eu(MinWaves<R, CNT, FEAT, WIDE>::value)))
+render_kernel(RenderArgs A, CamDev<R> cam) {
+  render_body<R, CNT, FEAT, WIDE>(A);
+}
+
+// The production kernels of the on-chip store with plain textures, held to 72 scalar
+// registers.  A SIMD admits eight waves of a kernel only up to 80 of them (measured: at 96,
+// which the register file's 800 would seem to allow eight times, the eighth wave never
+// becomes resident; shapes of 512 x 4 and 256 x 8 ran at the rate of 512 x 3 and 256 x 7).
+// The compiler keeps ~18 rarely used scalars in lanes of a vector register instead, which
+// costs 2 % at equal occupancy and buys the eighth wave: a second 1024-thread workgroup per
+// CU for scenes whose image leaves room for it, 256 x 8 for scenes without a hierarchy.
+// (The attribute takes a literal only, hence a kernel of its own and not a case of the
+// template above; the textured variants and the HBM store are short of vector registers
+// first and gain nothing.)
+template <uint32_t FEAT>
+__global__ void __launch_bounds__(M<float>::BT) __attribute__((amdgpu_waves_per_eu(6), amdgpu_num_sgpr(72)))
+render_kernel_lean(RenderArgs A, CamDev<float> cam) {
+  render_body<float, false, FEAT, false>(A);
 }
 
 // world.hit(camera ray through the pixel centre, 0.001, +inf) for every pixel.
@@ -1640,7 +1661,13 @@ const RenderKernel32 k32[2][2][5] = {{HT_FEAT_ROW(float, false, false), HT_FEAT_
 const RenderKernel64 k64[2][2][5] = {{HT_FEAT_ROW(double, false, false), HT_FEAT_ROW(double, true, false)},
                                      {HT_FEAT_ROW(double, false, true), HT_FEAT_ROW(double, true, true)}};
 #undef HT_FEAT_ROW
+// KFEAT_LEAN: the fp32 on-chip production kernels held to 72 scalar registers
+bool lean_variant(int precision, bool counters, uint32_t feat, bool wide) {
+  return (feat & KFEAT_LEAN) != 0u && precision == 0 && !counters && !wide && (feat & 3u) == 0u;
+}
+RenderKernel32 lean_kernel(uint32_t feat) { return (feat & FEAT_TRIS) ? render_kernel_lean<FEAT_TRIS> : render_kernel_lean<0>; }
 const void* render_kernel_ptr(int precision, bool counters, uint32_t feat, bool wide) {
+  if (lean_variant(precision, counters, feat, wide)) return reinterpret_cast<const void*>(lean_kernel(feat));
   return precision == 0 ? reinterpret_cast<const void*>(k32[wide ? 1 : 0][counters ? 1 : 0][feat_index(feat)])
                         : reinterpret_cast<const void*>(k64[wide ? 1 : 0][counters ? 1 : 0][feat_index(feat)]);
 }
@@ -1650,6 +1677,13 @@ const void* render_kernel_ptr(int precision, bool counters, uint32_t feat, bool 
 // never lowered, so threads that work out launch shapes for different scenes cannot undo
 // each other's setting between the query and the launch.
 constexpr uint32_t LDS_LIMIT_BYTES = 160u * 1024u;
+
+int render_max_waves_per_cu(int precision, bool counters, uint32_t feat, bool wide) {
+  return lean_variant(precision, counters, feat, wide) ? 32 : 28;
+}
+bool render_has_lean_variant(int precision, bool counters, uint32_t feat, bool wide) {
+  return lean_variant(precision, counters, feat | KFEAT_LEAN, wide);
+}
 
 int render_blocks_per_cu(int precision, bool counters, uint32_t feat, bool wide, int threads,
                          uint32_t lds_bytes) {
@@ -1670,7 +1704,10 @@ int render_blocks_per_cu(int precision, bool counters, uint32_t feat, bool wide,
 hipError_t launch_render(int precision, bool counters, uint32_t feat, const RenderArgs& a, const void* cam,
                          int grid_blocks, int threads, uint32_t lds_bytes, hipStream_t stream) {
   const int w = a.L.wide ? 1 : 0;
-  if (precision == 0) {
+  if (lean_variant(precision, counters, feat, a.L.wide != 0u)) {
+    hipLaunchKernelGGL(lean_kernel(feat), dim3(grid_blocks), dim3(threads), lds_bytes, stream, a,
+                       *static_cast<const CamDev<float>*>(cam));
+  } else if (precision == 0) {
     hipLaunchKernelGGL(k32[w][counters ? 1 : 0][feat_index(feat)], dim3(grid_blocks), dim3(threads), lds_bytes, stream,
                        a, *static_cast<const CamDev<float>*>(cam));
   } else {
