@@ -986,9 +986,11 @@ constexpr uint32_t TILE_ACC_BYTES = TILE_PIXELS * 3u * 8u;
 // the unit runs out the wave moves on to the next one at once while the
 // stragglers of the old unit are still in flight.
 // Waves per SIMD the register allocator must leave room for: the plain fp32 variants
-// are held to 80 VGPRs, so that 24 waves fit a CU next to the scene image.
+// are held to 80 VGPRs, so that 24 waves fit a CU next to the scene image; the on-chip variant
+// with image textures needs 74 and is held to the 72 of seven waves (two registers spilled:
+// scene.json 34.0 -> 35.2, checker.json 25.9 -> 26.6 G samples/s).
 template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
-struct MinWaves { static constexpr int value = (sizeof(R) == 4 && !CNT) ? ((FEAT & 3u) == 0u ? 6 : ((FEAT & 3u) == 3u ? 4 : 5)) : 1; };
+struct MinWaves { static constexpr int value = (sizeof(R) == 4 && !CNT) ? ((FEAT & 3u) == 0u ? 6 : ((FEAT & 3u) == 3u ? 4 : ((FEAT & 3u) == 2u && !WIDE ? 7 : 5))) : 1; };
 
 template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
 __device__ __forceinline__ void render_body(const RenderArgs& A) {
