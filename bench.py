@@ -211,9 +211,6 @@ def main():
         accum.zero_()
         ctr = scene.render_accumulate(cam, cparams, accum.data_ptr(), stream, want_stats=True)
         flops_per_sample = algorithmic_flops(ctr) / ctr["samples"]
-        # the launch shape of the production kernel (the counters build has its own)
-        last_stats = scene.render_accumulate(cam, ht.make_params(W, H, 1, sample_offset=first, seed=2025, device=local_rank),
-                                             accum.data_ptr(), stream, want_stats=True)
         rank_samples = W * H * count * args.steps
         achieved = flops_per_sample * rank_samples / max(ksec, 1e-9) / 1e12
         info = scene.info()
@@ -270,9 +267,9 @@ def main():
                 "traffic": traffic,
                 "traffic_note": traffic_note,
                 # on-chip scenes with plain textures whose image leaves room for 32 waves per CU run
-                # the 72-scalar-register variant (render_kernel_lean), the others render_kernel
-                "kernel": "render_kernel_lean or render_kernel<float,false,...>, whichever the library picked: %d threads x %d per CU"
-                          % (last_stats["block_threads"], last_stats["blocks_per_cu"]),
+                # the 80-scalar-register variant (render_kernel_lean), the others render_kernel
+                "kernel": "render_kernel_lean<FEAT> (80 scalar registers, 32 waves per CU) or render_kernel<float,false,FEAT,WIDE>: "
+                          "the variant the library picks for the scene; the rocprofv3 trace names it",
                 "flops_per_sample": flops_per_sample,
                 "kernel_ms_per_launch": ksec / max(launches, 1) * 1e3,
                 "kernel_timing": kernel_timing,

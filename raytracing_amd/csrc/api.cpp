@@ -184,7 +184,7 @@ int launch_shape(ht_scene* s, int prec, bool counters, LaunchShape& out) {
     const uint32_t base_feat = s->feat | (L.tree_kinds == TREE_TRIANGLES ? KFEAT_TRIS : 0u);
     LaunchShape best;
     const int forced = g_block_threads.load();
-    // The variant held to 72 scalar registers runs 2-3 % slower at equal occupancy (it keeps
+    // The variant held to 80 scalar registers runs 1-2 % slower at equal occupancy (it keeps
     // some scalars in vector lanes) and is the only one a CU holds 32 waves of: it is taken
     // when that buys a larger shape (dragon: 1024 x 2 instead of 768 x 2, +5 %; Cornell box:
     // 256 x 8 instead of 256 x 7, +6 %), not otherwise (random.json: 768 x 2 either way).

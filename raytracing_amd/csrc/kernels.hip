@@ -1270,18 +1270,18 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
   render_body<R, CNT, FEAT, WIDE>(A);
 }
 
-// The production kernels of the on-chip store with plain textures, held to 72 scalar
-// registers.  A SIMD admits eight waves of a kernel only up to 80 of them (measured: at 96,
-// which the register file's 800 would seem to allow eight times, the eighth wave never
-// becomes resident; shapes of 512 x 4 and 256 x 8 ran at the rate of 512 x 3 and 256 x 7).
-// The compiler keeps ~18 rarely used scalars in lanes of a vector register instead, which
-// costs 2 % at equal occupancy and buys the eighth wave: a second 1024-thread workgroup per
+// The production kernels of the on-chip store with plain textures, held to 80 scalar
+// registers.  A SIMD admits eight waves of a kernel only up to 80 of them (measured: at 86
+// and at 96, which the register file's 800 would seem to allow eight times, the eighth wave
+// never becomes resident; shapes of 512 x 4 and 256 x 8 ran at the rate of 512 x 3 and
+// 256 x 7).  The compiler keeps ~11 rarely used scalars in lanes of a vector register
+// instead, which costs 1-2 % at equal occupancy and buys the eighth wave: a second 1024-thread workgroup per
 // CU for scenes whose image leaves room for it, 256 x 8 for scenes without a hierarchy.
 // (The attribute takes a literal only, hence a kernel of its own and not a case of the
 // template above; the textured variants and the HBM store are short of vector registers
 // first and gain nothing.)
 template <uint32_t FEAT>
-__global__ void __launch_bounds__(M<float>::BT) __attribute__((amdgpu_waves_per_eu(6), amdgpu_num_sgpr(72)))
+__global__ void __launch_bounds__(M<float>::BT) __attribute__((amdgpu_waves_per_eu(6), amdgpu_num_sgpr(80)))
 render_kernel_lean(RenderArgs A, CamDev<float> cam) {
   render_body<float, false, FEAT, false>(A);
 }
@@ -1663,7 +1663,7 @@ const RenderKernel32 k32[2][2][5] = {{HT_FEAT_ROW(float, false, false), HT_FEAT_
 const RenderKernel64 k64[2][2][5] = {{HT_FEAT_ROW(double, false, false), HT_FEAT_ROW(double, true, false)},
                                      {HT_FEAT_ROW(double, false, true), HT_FEAT_ROW(double, true, true)}};
 #undef HT_FEAT_ROW
-// KFEAT_LEAN: the fp32 on-chip production kernels held to 72 scalar registers
+// KFEAT_LEAN: the fp32 on-chip production kernels held to 80 scalar registers
 bool lean_variant(int precision, bool counters, uint32_t feat, bool wide) {
   return (feat & KFEAT_LEAN) != 0u && precision == 0 && !counters && !wide && (feat & 3u) == 0u;
 }
