@@ -455,20 +455,32 @@ __device__ __forceinline__ void sphere_pair_test(const Scene& sc, const Ray<R>& 
   sphere_test<R, CNT>(sc, ray, tv, single | idx, KIND_SPHERE, idx, t_min, cnt);
   if (pair) sphere_test<R, CNT>(sc, ray, tv, single | (idx + 1u), KIND_SPHERE, idx + 1u, t_min, cnt);
 }
-template <typename R, bool CNT>
-__device__ __forceinline__ void rect_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t ref,
-                                          uint32_t kind, uint32_t idx, R t_min, Cnt& cnt) {
-  // XY / XZ / YZ rect, Hittable.scala:55-92
+// XY / XZ / YZ rect, Hittable.scala:55-92.  K = the axis the rect is perpendicular to, a
+// compile-time fact of each of the three copies: picking the components with selects on the
+// kind cost eight of them per test, and 1/d of that axis is in the ray already.  The hoisted
+// primitives are the same for every lane, so there the three copies sit behind scalar branches
+// (the Cornell box tests six rects per ray this way).
+template <typename R, bool CNT, int K>
+__device__ __forceinline__ void rect_test_axis(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t ref,
+                                               uint32_t idx, R t_min, Cnt& cnt) {
   if (CNT) cnt.v[CTR_RECT]++;
   RectGeom<R> g = load_rect<R>(sc, idx);
-  R oa, ob, ok_, da, db, dk;
-  rect_axes<R>(kind, ray.o, oa, ob, ok_);
-  rect_axes<R>(kind, ray.d, da, db, dk);
-  R t = (g.k - ok_) * M<R>::rcp(dk);
+  // (a, b, k) axes: XY -> (x, y, z), XZ -> (x, z, y), YZ -> (y, z, x)
+  const R oa = K == 0 ? ray.o.y : ray.o.x, ob = K == 2 ? ray.o.y : ray.o.z, ok_ = K == 2 ? ray.o.z : (K == 1 ? ray.o.y : ray.o.x);
+  const R da = K == 0 ? ray.d.y : ray.d.x, db = K == 2 ? ray.d.y : ray.d.z;
+  const R ik = K == 2 ? ray.inv.z : (K == 1 ? ray.inv.y : ray.inv.x);  // 1 / d_k
+  R t = (g.k - ok_) * ik;
   R a = oa + t * da, bb = ob + t * db;
   const bool ok = t >= t_min && t < tv.best_t && a >= g.a0 && a <= g.a1 && bb >= g.b0 && bb <= g.b1;
   tv.best_t = ok ? t : tv.best_t;
   tv.best_ref = ok ? ref : tv.best_ref;
+}
+template <typename R, bool CNT>
+__device__ __forceinline__ void rect_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t ref,
+                                          uint32_t kind, uint32_t idx, R t_min, Cnt& cnt) {
+  if (kind == KIND_XYRECT) rect_test_axis<R, CNT, 2>(sc, ray, tv, ref, idx, t_min, cnt);
+  else if (kind == KIND_XZRECT) rect_test_axis<R, CNT, 1>(sc, ray, tv, ref, idx, t_min, cnt);
+  else rect_test_axis<R, CNT, 0>(sc, ray, tv, ref, idx, t_min, cnt);
 }
 template <typename R, bool CNT, bool WIDE>
 __device__ __forceinline__ void prim_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t ref,
@@ -661,17 +673,24 @@ __device__ __forceinline__ void hit_uv(const Scene& sc, const Ray<R>& ray, const
   }
 }
 
-// Perlin.noise (Texture.scala:44-76)
+// Perlin.noise (Texture.scala:44-76).  The fused multiply-adds are written out and the
+// compiler's own contraction is off in these two functions: seven octaves of this sum feed a
+// sine, and left to itself the compiler fuses them differently in every kernel the function
+// is inlined into, so the variants of the renderer would disagree in the last bit of a fifth
+// of a Perlin scene's sums.
+__device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <typename R>
 __device__ __forceinline__ R perlin_noise(const Scene& sc, uint32_t table, V3<R> p) {
+#pragma clang fp contract(off)
   const uint8_t* tb = sc.base + sc.L.perlin + table * sc.L.perlin_stride;
   const uint8_t* perm = tb + 256u * 4u * (uint32_t)sizeof(R);
   R fx = M<R>::floor(p.x), fy = M<R>::floor(p.y), fz = M<R>::floor(p.z);
   R u = p.x - fx, v = p.y - fy, w = p.z - fz;
   int i = (int)fx, j = (int)fy, k = (int)fz;
-  R uu = u * u * ((R)3 - (R)2 * u);
-  R vv = v * v * ((R)3 - (R)2 * v);
-  R ww = w * w * ((R)3 - (R)2 * w);
+  R uu = u * u * fma_r((R)-2, u, (R)3);
+  R vv = v * v * fma_r((R)-2, v, (R)3);
+  R ww = w * w * fma_r((R)-2, w, (R)3);
   R sum = 0;
 #pragma unroll
   for (int di = 0; di < 2; ++di)
@@ -683,16 +702,18 @@ __device__ __forceinline__ R perlin_noise(const Scene& sc, uint32_t table, V3<R>
                      (uint32_t)perm[512 + ((k + dk) & 255)];
         typename M<R>::R4 c = *(const typename M<R>::R4*)(tb + g * (uint32_t)(4 * sizeof(R)));
         R wx = di ? uu : (R)1 - uu, wy = dj ? vv : (R)1 - vv, wz = dk ? ww : (R)1 - ww;
-        sum += wx * wy * wz * (c.x * (u - (R)di) + c.y * (v - (R)dj) + c.z * (w - (R)dk));
+        const R d = fma_r(c.z, w - (R)dk, fma_r(c.y, v - (R)dj, c.x * (u - (R)di)));
+        sum = fma_r(wx * wy * wz, d, sum);
       }
   return sum;
 }
 // Perlin.turb, depth 7 (Texture.scala:78-88)
 template <typename R>
 __device__ __forceinline__ R perlin_turb(const Scene& sc, uint32_t table, V3<R> p) {
+#pragma clang fp contract(off)
   R accum = 0, weight = 1;
   for (int i = 0; i < 7; ++i) {
-    accum += weight * perlin_noise<R>(sc, table, p);
+    accum = fma_r(weight, perlin_noise<R>(sc, table, p), accum);
     p = (R)2 * p;
     weight *= (R)0.5;
   }
