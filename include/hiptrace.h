@@ -341,7 +341,8 @@ int ht_scene_get_info(const ht_scene* scene, ht_scene_info* out);
 /*   "wavefront"         1: fp32 renders run the wavefront variant of the path tracer (one kernel
  *                       per stage: generate, trace, shade with compaction, reduce; path state in
  *                       device memory between them) instead of the persistent kernel; same paths,
- *                       same sums.  The calls then synchronise with the stream.
+ *                       same sums up to the compiler's placement of fused multiply-adds (a hit
+ *                       point may differ in its last bit).  The calls then synchronise with the stream.
  *   "wavefront_paths"   paths in flight of the wavefront variant (2^12..2^26, default 2^24)
  *   "wavefront_refill"  idle lanes of a trace wave that trigger a refill from the ray list (default 32) */
 int ht_set_option(const char* name, int value);
