@@ -19,6 +19,7 @@
 
 #include "../../include/hiptrace.h"
 #include "host_scene.h"
+#include "bvh_gpu.h"
 #include "kernels.h"
 
 using namespace ht;
@@ -109,6 +110,7 @@ std::atomic<int> g_node_den{2}, g_wait_num{1000}, g_wait_den{1};
 std::atomic<int> g_default_batch{1024};
 std::atomic<int> g_chunk{0};  // 0: by launch size
 std::atomic<int> g_chunk_tail{4};
+std::atomic<int> g_gpu_bvh_min{0};   // > 0: hierarchies over at least this many primitives are built on the device
 std::atomic<int> g_force_hbm{0};     // scenes created while set keep their image in HBM
 std::atomic<int> g_wavefront{0};      // 1: fp32 renders run the wavefront variant
 std::atomic<int> g_wavefront_cap{1 << 24};  // paths in flight of the wavefront variant
@@ -532,6 +534,7 @@ int ht_set_option(const char* name, int value) {
   if (!strcmp(name, "node_den")) { g_node_den = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "wait_ratio_num")) { g_wait_num = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "wait_ratio_den")) { g_wait_den = std::max(1, value); return HT_OK; }
+  if (!strcmp(name, "gpu_bvh")) { g_gpu_bvh_min = std::max(0, value); return HT_OK; }
   if (!strcmp(name, "force_hbm_scene")) { g_force_hbm = value ? 1 : 0; return HT_OK; }
   if (!strcmp(name, "wavefront")) { g_wavefront = value ? 1 : 0; return HT_OK; }
   if (!strcmp(name, "wavefront_refill")) { g_wavefront_refill = std::min(64, std::max(1, value)); return HT_OK; }
@@ -552,6 +555,19 @@ void ht_scene_destroy(ht_scene* s) {
   }
   delete s;
 }
+
+namespace {
+// BuildOptions::external_bvh: the linear BVH of bvh_gpu.hip on the scene's device
+bool device_bvh(void* ctx, uint32_t n, const float* boxes, const float cent_lo[3], const float cent_hi[3],
+                ht::ExternalNode* nodes) {
+  static_assert(sizeof(ht::ExternalNode) == sizeof(ht::LbvhNode) && ht::EXTERNAL_LEAF == ht::LBVH_LEAF, "one layout");
+  DeviceGuard g(*static_cast<const int*>(ctx));
+  if (!g.ok) return false;
+  const hipError_t e = ht::lbvh_build(n, boxes, cent_lo, cent_hi, reinterpret_cast<ht::LbvhNode*>(nodes));
+  if (e != hipSuccess) (void)hipGetLastError();
+  return e == hipSuccess;
+}
+}  // namespace
 
 int ht_scene_create(const ht_scene_desc* desc, int device, ht_scene** out) {
   if (!out) return fail(HT_E_INVALID, "out is NULL");
@@ -580,6 +596,9 @@ int ht_scene_create(const ht_scene_desc* desc, int device, ht_scene** out) {
     BuildOptions opt;
     opt.lds_bytes = (uint32_t)prop.sharedMemPerBlock;  // 160 KiB on gfx950
     opt.force_hbm = g_force_hbm.load() != 0;
+    opt.external_bvh = device_bvh;
+    opt.external_ctx = &device;
+    opt.external_min_prims = g_gpu_bvh_min.load();
     rc = build_host_scene(desc, s->hs, err, opt);
   } catch (const std::exception& e) {
     delete s;

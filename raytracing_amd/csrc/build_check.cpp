@@ -2,12 +2,16 @@
 // structural invariants of the hierarchy and of the scene image out.  Built with
 // AddressSanitizer + UBSan by `make build_check`; no device code, no HIP runtime.
 //
-//   build_check <n_spheres> <n_triangles> <n_rects> <seed> [force_hbm]
+//   build_check <n_spheres> <n_triangles> <n_rects> <seed> [force_hbm [external]]
+// external: 1 = the hierarchy comes from a stand-in for the device builder (median splits),
+// 2 = from one that loses a primitive, 3 = from one that is a chain as deep as the scene;
+// 2 and 3 must be refused and the host's own hierarchy used.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <random>
 #include <string>
 #include <vector>
@@ -135,6 +139,51 @@ struct Walk {
   }
 };
 
+// stand-ins for the device builder
+struct Standin {
+  int mode;
+  uint32_t n;
+  const float* boxes;
+  ExternalNode* nodes;
+  uint32_t next;
+  std::vector<uint32_t> order;
+  void box_of(uint32_t b, uint32_t e, float* lo, float* hi) {
+    for (int a = 0; a < 3; ++a) { lo[a] = 3e38f; hi[a] = -3e38f; }
+    for (uint32_t k = b; k < e; ++k)
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = fminf(lo[a], boxes[(size_t)order[k] * 6 + a]);
+        hi[a] = fmaxf(hi[a], boxes[(size_t)order[k] * 6 + 3 + a]);
+      }
+  }
+  uint32_t build(uint32_t b, uint32_t e, int level) {  // e - b >= 2
+    const uint32_t idx = next++;
+    uint32_t mid = mode == 3 ? b + 1 : b + (e - b) / 2;
+    const int axis = level % 3;
+    if (mode != 3)
+      std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e, [&](uint32_t x, uint32_t y) {
+        return boxes[(size_t)x * 6 + axis] + boxes[(size_t)x * 6 + 3 + axis] < boxes[(size_t)y * 6 + axis] + boxes[(size_t)y * 6 + 3 + axis];
+      });
+    const uint32_t r[2][2] = {{b, mid}, {mid, e}};
+    for (int c = 0; c < 2; ++c) {
+      box_of(r[c][0], r[c][1], nodes[idx].lo[c], nodes[idx].hi[c]);
+      nodes[idx].child[c] = r[c][1] - r[c][0] == 1 ? (EXTERNAL_LEAF | order[r[c][0]]) : build(r[c][0], r[c][1], level + 1);
+    }
+    return idx;
+  }
+};
+bool standin_builder(void* ctx, uint32_t n, const float* boxes, const float*, const float*, ExternalNode* nodes) {
+  Standin s{*(int*)ctx, n, boxes, nodes, 0, {}};
+  s.order.resize(n);
+  for (uint32_t i = 0; i < n; ++i) s.order[i] = i;
+  s.build(0, n, 0);
+  if (s.mode == 2) {  // the last leaf reference names the first primitive again
+    for (uint32_t i = n - 1; i-- > 0;)
+      for (int c = 1; c >= 0; --c)
+        if (nodes[i].child[c] & EXTERNAL_LEAF) { nodes[i].child[c] = EXTERNAL_LEAF | s.order[0]; return true; }
+  }
+  return true;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -202,6 +251,12 @@ int main(int argc, char** argv) {
   std::string err;
   BuildOptions opt;
   opt.force_hbm = force_hbm;
+  int ext_mode = argc > 6 ? atoi(argv[6]) : 0;
+  if (ext_mode) {
+    opt.external_bvh = standin_builder;
+    opt.external_ctx = &ext_mode;
+    opt.external_min_prims = 2;
+  }
   int rc = build_host_scene(&d, hs, err, opt);
   if (rc != HT_OK) { fprintf(stderr, "build failed: %d %s\n", rc, err.c_str()); return 1; }
 
@@ -255,7 +310,7 @@ int main(int argc, char** argv) {
     }
   }
   if (g_fail) { fprintf(stderr, "%d check(s) failed\n", g_fail); return 1; }
-  printf("ok prims=%d nodes=%zu depth=%d pairs=%d hoisted=%zu wide32=%u wide64=%u image32=%u\n", n, hs.nodes.size(), hs.depth,
-         w.pairs, hs.hoist.size(), hs.layout32.wide, hs.layout64.wide, hs.layout32.total_bytes);
+  printf("ok prims=%d nodes=%zu depth=%d pairs=%d hoisted=%zu wide32=%u wide64=%u image32=%u external=%d\n", n, hs.nodes.size(),
+         hs.depth, w.pairs, hs.hoist.size(), hs.layout32.wide, hs.layout64.wide, hs.layout32.total_bytes, hs.external_bvh_used ? 1 : 0);
   return 0;
 }

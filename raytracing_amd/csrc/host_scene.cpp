@@ -539,6 +539,71 @@ bool textures_acyclic(const HostScene& hs) {
 
 }  // namespace
 
+// A hierarchy that came from outside -> the host's node array, depth first, with leaves of
+// two where both children of a node below the root are single triangles or single ordinary
+// spheres.  Everything about the input is checked (it was computed on another device): every
+// inner node and every primitive reached exactly once, indices in range, depth within
+// `max_levels`.  Returns false if anything is off; `nodes` and the pair lists are then garbage.
+struct ExternalConverter {
+  const std::vector<ExternalNode>& in;
+  const std::vector<Item>& items;
+  std::vector<BvhNode>& nodes;
+  std::vector<std::pair<uint32_t, uint32_t>>&tri_pairs, &sph_pairs;
+  std::vector<uint8_t> node_seen, item_seen;
+  int max_levels, max_level = 0;
+  bool ok = true;
+
+  uint32_t leaf(uint32_t r) {
+    const uint32_t i = r & ~EXTERNAL_LEAF;
+    if (i >= items.size() || item_seen[i]) { ok = false; return WREF_EMPTY; }
+    item_seen[i] = 1;
+    return items[i].ref;
+  }
+  uint32_t convert(uint32_t g, int level) {
+    if (!ok) return WREF_EMPTY;
+    if (g >= in.size() || node_seen[g] || level >= max_levels) { ok = false; return WREF_EMPTY; }
+    node_seen[g] = 1;
+    const ExternalNode& e = in[g];
+    if (level > 0 && (e.child[0] & EXTERNAL_LEAF) && (e.child[1] & EXTERNAL_LEAF)) {
+      const uint32_t a = leaf(e.child[0]), b = leaf(e.child[1]);
+      if (!ok) return WREF_EMPTY;
+      const uint32_t ka = (a >> WREF_KIND_SHIFT) & 7u, kb = (b >> WREF_KIND_SHIFT) & 7u;
+      if (ka == kb && (ka == KIND_TRIANGLE || ka == KIND_SPHERE)) {
+        auto& list = ka == KIND_TRIANGLE ? tri_pairs : sph_pairs;
+        list.emplace_back(a & WREF_INDEX_MASK, b & WREF_INDEX_MASK);
+        return WREF_LEAF | ((ka == KIND_TRIANGLE ? KIND_TRI_PAIR : KIND_SPH_PAIR) << WREF_KIND_SHIFT) | (uint32_t)(list.size() - 1);
+      }
+      return emit(e, a, b, level);
+    }
+    const uint32_t idx = (uint32_t)nodes.size();
+    nodes.emplace_back();
+    max_level = std::max(max_level, level + 1);
+    uint32_t c[2];
+    for (int k = 0; k < 2; ++k)
+      c[k] = (e.child[k] & EXTERNAL_LEAF) ? leaf(e.child[k]) : convert(e.child[k], level + 1);
+    fill(idx, e, c[0], c[1]);
+    return idx;
+  }
+  uint32_t emit(const ExternalNode& e, uint32_t a, uint32_t b, int level) {
+    const uint32_t idx = (uint32_t)nodes.size();
+    nodes.emplace_back();
+    max_level = std::max(max_level, level + 1);
+    fill(idx, e, a, b);
+    return idx;
+  }
+  void fill(uint32_t idx, const ExternalNode& e, uint32_t c0, uint32_t c1) {
+    BvhNode& nd = nodes[idx];
+    for (int k = 0; k < 2; ++k)
+      for (int a = 0; a < 3; ++a) {
+        nd.lo[k][a] = e.lo[k][a];
+        nd.hi[k][a] = e.hi[k][a];
+        if (!(e.lo[k][a] <= e.hi[k][a])) ok = false;  // NaN, or a box turned inside out
+      }
+    nd.child[0] = c0;
+    nd.child[1] = c1;
+  }
+};
+
 // LDS a 256-thread workgroup needs beside the image: stacks + tile sums (kernels.hip)
 static uint32_t lds_beside_image(uint32_t depth) {
   return ((256u * 2u * (depth + 2u) + 15u) & ~15u) + (256u / 64u) * 64u * 3u * 8u;
@@ -736,6 +801,7 @@ int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err, co
   }
   hs.nodes.clear();
   hs.depth = 0;
+  hs.external_bvh_used = false;
   std::vector<std::pair<uint32_t, uint32_t>> tri_pairs, sph_pairs;  // leaves of two, from the builder
   if (nb == 1) {
     // like the reference's BVH(only, only) (BVH.scala:30): the same leaf twice
@@ -756,8 +822,42 @@ int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err, co
     int wide_levels = 1;
     while ((1 << std::min(wide_levels - 1, 30)) < nb && wide_levels < WIDE_STACK_MAX_DEPTH) wide_levels++;
     wide_levels = std::min(WIDE_STACK_MAX_DEPTH, std::max(18, wide_levels));
+    const int wide_levels_cap = WIDE_STACK_MAX_DEPTH;  // what the HBM store's traversal stack can be sized for
     // A large scene: the top of the hierarchy here, the subtrees of up to JOB_MAX_ITEMS
     // primitives on several threads, each into its own arrays, appended in job order.
+    const int max_levels = small ? STACK_MAX_DEPTH : wide_levels_cap;
+    if (opt.external_bvh && opt.external_min_prims > 0 && nb >= std::max(2, opt.external_min_prims)) {
+      // the other builder works on float boxes rounded outward: still boxes around the primitives
+      std::vector<float> fb((size_t)nb * 6);
+      float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+      for (int k = 0; k < nb; ++k)
+        for (int a = 0; a < 3; ++a) {
+          fb[(size_t)k * 6 + a] = round_down<float>(items[k].box.lo[a]);
+          fb[(size_t)k * 6 + 3 + a] = round_up<float>(items[k].box.hi[a]);
+          const float c = (float)items[k].c[a];
+          clo[a] = std::min(clo[a], c);
+          chi[a] = std::max(chi[a], c);
+        }
+      std::vector<ExternalNode> ext((size_t)nb - 1);
+      if (opt.external_bvh(opt.external_ctx, (uint32_t)nb, fb.data(), clo, chi, ext.data())) {
+        ExternalConverter cv{ext, items, hs.nodes, tri_pairs, sph_pairs, std::vector<uint8_t>(ext.size(), 0),
+                             std::vector<uint8_t>((size_t)nb, 0), max_levels};
+        hs.nodes.reserve(ext.size());
+        const uint32_t r = cv.convert(0u, 0);
+        bool all = cv.ok && r == 0u;
+        for (size_t k = 0; all && k < cv.node_seen.size(); ++k) all = cv.node_seen[k] != 0;
+        for (size_t k = 0; all && k < cv.item_seen.size(); ++k) all = cv.item_seen[k] != 0;
+        if (all) {
+          hs.depth = cv.max_level;
+          hs.external_bvh_used = true;
+        } else {  // not a hierarchy over these primitives, or too deep for the traversal stack
+          hs.nodes.clear();
+          tri_pairs.clear();
+          sph_pairs.clear();
+        }
+      }
+    }
+    if (!hs.external_bvh_used) {
     std::vector<BuildJob> jobs;
     hs.nodes.resize((size_t)nb);  // a hierarchy over nb primitives has at most nb - 1 nodes
     Builder top{hs.nodes.data(), items};
@@ -841,6 +941,7 @@ int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err, co
         }
     }
     hs.nodes.resize(n_nodes);
+    }
   }
   {
     // the two primitives of a pair must be neighbours in the array of their kind: flagged

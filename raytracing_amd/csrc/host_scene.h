@@ -40,14 +40,33 @@ struct HostScene {
   std::vector<BvhNode> nodes;       // hierarchy over the remaining primitives (may be empty)
   double root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
   int depth = 0;
+  bool external_bvh_used = false;   // the hierarchy came from BuildOptions::external_bvh
 
   SceneLayout layout32{}, layout64{};
   std::vector<uint8_t> blob32, blob64;
 };
 
+// A hierarchy built elsewhere (on the device: bvh_gpu.h).  Inner node: the boxes of its two
+// children and their references: an inner node's index, or EXTERNAL_LEAF | index of the
+// primitive among the n boxes handed over.  Node 0 is the root, n - 1 nodes in all.
+constexpr uint32_t EXTERNAL_LEAF = 0x80000000u;
+struct ExternalNode {
+  float lo[2][3], hi[2][3];
+  uint32_t child[2];
+};
+// boxes: n x (lo.xyz, hi.xyz), rounded outward; cent_lo / cent_hi: bounds of the box centres.
+// Returns false when it could not build (the host builds then).
+typedef bool (*ExternalBvhBuilder)(void* ctx, uint32_t n, const float* boxes, const float cent_lo[3],
+                                   const float cent_hi[3], ExternalNode* nodes);
+
 struct BuildOptions {
   uint32_t lds_bytes = 160u * 1024u;  // LDS one workgroup may use on the target device
   bool force_hbm = false;             // put the scene image in the HBM store even if it fits on chip
+  // hierarchies over at least external_min_prims primitives are built by external_bvh, if set
+  // (its result is checked, and the host's own builder takes over when it does not hold up)
+  ExternalBvhBuilder external_bvh = nullptr;
+  void* external_ctx = nullptr;
+  int external_min_prims = 0;
 };
 
 // Validates `desc` and fills `out`; returns HT_OK or an error code with `err` set.

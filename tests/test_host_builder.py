@@ -57,3 +57,22 @@ def test_store_follows_the_size(checker):
     assert run(4097, 0, 0, 3)["wide32"] == "1"   # more than 4096 of a kind
     f = run(1500, 0, 0, 3)
     assert f["wide32"] == "0" and f["wide64"] == "1"  # the fp64 image is twice the size
+
+
+@pytest.mark.parametrize("n_sph,n_tri,n_rect", [(40, 41, 5), (2, 871, 0), (3000, 70000, 10), (1, 1, 9)])
+def test_hierarchy_from_another_builder_is_checked_and_used(checker, n_sph, n_tri, n_rect):
+    """BuildOptions::external_bvh (the device builder's hook) with CPU stand-ins: a sound
+    hierarchy is converted (leaves of two included) and passes every check of the walk; one
+    that loses a primitive, or is deeper than the traversal stack, is refused and the host
+    builds its own."""
+    def run(mode):
+        r = subprocess.run([checker, str(n_sph), str(n_tri), str(n_rect), "5", "0", str(mode)], capture_output=True,
+                           text=True, timeout=120, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+        assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout + r.stderr[-3000:]
+        return dict(kv.split("=") for kv in r.stdout.split()[1:])
+    own, good, lossy = run(0), run(1), run(2)
+    assert own["external"] == "0" and good["external"] == "1"
+    assert lossy["external"] == "0" and lossy["nodes"] == own["nodes"] and lossy["depth"] == own["depth"]
+    if 60 < n_sph + n_tri + n_rect < 2000:  # a chain over that many primitives is deeper than any stack
+        chain = run(3)                      # (the stand-in recurses once per level: small scenes only)
+        assert chain["external"] == "0" and chain["nodes"] == own["nodes"]
