@@ -186,10 +186,11 @@ int launch_shape(ht_scene* s, int prec, bool counters, LaunchShape& out) {
     const uint32_t base_feat = s->feat | (L.tree_kinds == TREE_TRIANGLES ? KFEAT_TRIS : 0u);
     LaunchShape best;
     const int forced = g_block_threads.load();
-    // The variant held to 80 scalar registers runs 1-2 % slower at equal occupancy (it keeps
-    // some scalars in vector lanes) and is the only one a CU holds 32 waves of: it is taken
-    // when that buys a larger shape (dragon: 1024 x 2 instead of 768 x 2, +5 %; Cornell box:
-    // 256 x 8 instead of 256 x 7, +6 %), not otherwise (random.json: 768 x 2 either way).
+    // The variants held to 80 / 96 scalar registers run 1-3 % slower at equal occupancy (they
+    // keep some scalars in vector lanes) and are the only ones a CU holds 32 / 28 waves of: they
+    // are taken when that buys a larger shape (dragon: 1024 x 2 instead of 768 x 2, +5 %; Cornell
+    // box: 256 x 8 instead of 256 x 7, +6 %; HBM store: 256 x 7 instead of 256 x 6 or 5), not
+    // otherwise (random.json: 768 x 2 either way).
     for (int lean = 0; lean <= (render_has_lean_variant(prec, counters, base_feat, L.wide != 0u) ? 1 : 0); ++lean) {
       const uint32_t kfeat = base_feat | (lean ? KFEAT_LEAN : 0u);
       for (int t = 256; t <= (int)max_block_threads(prec); t += 128) {
@@ -200,10 +201,10 @@ int launch_shape(ht_scene* s, int prec, bool counters, LaunchShape& out) {
         // several workgroups share a CU well only when each fills the four SIMDs evenly: two
         // groups of 14 waves (measured on the Cornell box) ran 20 % slower than two of 12
         if (b > 1 && t % 256 != 0) b = 1;
-        // Most render kernels use 96 to 106 scalar registers, and a SIMD admits at most seven
-        // waves of a kernel that uses more than 80 (the occupancy API does not know and answers
-        // eight): a workgroup promised beyond 28 waves per CU never becomes resident (measured
-        // on the dragon: "1024 x 2" of the 96-register kernel 20.1, 768 x 2 24.3 G samples/s).
+        // A SIMD admits fewer waves of a kernel with many scalar registers than the occupancy
+        // API answers (it says eight for all of these): a workgroup promised beyond the real
+        // limit is accepted and never becomes resident (measured on the dragon: "1024 x 2" of
+        // the 96-register kernel 20.1, 768 x 2 24.3 G samples/s).
         const int forced_waves = g_max_waves_per_cu.load();
         const int max_waves = forced_waves > 0 ? forced_waves : render_max_waves_per_cu(prec, counters, kfeat, L.wide != 0u);
         if (b * t > max_waves * 64) b = max_waves * 64 / t;

@@ -263,6 +263,35 @@ struct Trav {
   R best_t;
 };
 
+// The traversal stacks in LDS: one row per level, [level][thread], so that the lanes of a wave
+// never meet in a bank.  On-chip store: 16-bit entries.  HBM store: a reference has 24
+// significant bits (scene_layout.h) and an entry is three bytes, a row being the threads' low
+// halves followed by their third bytes: with 4-byte entries a hierarchy of 17 levels takes
+// 100 bytes of LDS per lane (tile sums included) and six 256-thread workgroups fill a CU, at
+// three bytes 81 and seven (packing and the second LDS access cost 3 % at equal occupancy).
+// `addr` is the byte address of the lane's low half.
+template <bool WIDE>
+__device__ __forceinline__ uint32_t stack_hi_offset() {  // from a lane's low half to its third byte
+  return WIDE ? 2u * blockDim.x - threadIdx.x : 0u;
+}
+template <bool WIDE>
+__device__ __forceinline__ uint32_t stack_load(const uint8_t* lds, uint32_t addr) {
+  const uint32_t lo = *(const uint16_t*)(lds + addr);
+  if constexpr (!WIDE) return lo;
+  const uint32_t c = lo | ((uint32_t)lds[addr + stack_hi_offset<WIDE>()] << 16);
+  return (c & 0xFFFFFu) | ((c & 0xF00000u) << 8);
+}
+template <bool WIDE>
+__device__ __forceinline__ void stack_store(uint8_t* lds, uint32_t addr, uint32_t ref) {
+  if constexpr (!WIDE) {
+    *(uint16_t*)(lds + addr) = (uint16_t)ref;
+  } else {
+    const uint32_t c = (ref & 0xFFFFFu) | ((ref >> 8) & 0xF00000u);
+    *(uint16_t*)(lds + addr) = (uint16_t)c;
+    lds[addr + stack_hi_offset<WIDE>()] = (uint8_t)(c >> 16);
+  }
+}
+
 template <typename R, bool WIDE>
 __device__ __forceinline__ void trav_begin(Trav<R>& tv, uint32_t stack_level1) {
   tv.cur = 0;  // root is inner node 0
@@ -518,9 +547,8 @@ __device__ __forceinline__ void leaf_test(const Scene& sc, const Ray<R>& ray, Tr
 // operations are free of branches.
 template <typename R, bool WIDE>
 __device__ __forceinline__ uint32_t trav_pop(Trav<R>& tv, const uint8_t* lds) {
-  typedef typename RefT<WIDE>::stack_t stack_t;
-  tv.sp -= blockDim.x * (uint32_t)sizeof(stack_t);  // one level down
-  return (uint32_t)*(const stack_t*)(lds + tv.sp);
+  tv.sp -= blockDim.x * RefT<WIDE>::STACK_ENTRY;  // one level down
+  return stack_load<WIDE>(lds, tv.sp);
 }
 
 // Inner node: slab-test both children, descend into the nearer one that is hit
@@ -528,11 +556,10 @@ __device__ __forceinline__ uint32_t trav_pop(Trav<R>& tv, const uint8_t* lds) {
 template <typename R, bool CNT, bool WIDE>
 __device__ __forceinline__ void node_step(const Scene& sc, const Ray<R>& ray, Trav<R>& tv,
                                           uint8_t* lds, R t_min, Cnt& cnt) {
-  typedef typename RefT<WIDE>::stack_t stack_t;
-  const uint32_t LEVEL = blockDim.x * (uint32_t)sizeof(stack_t);
+  const uint32_t LEVEL = blockDim.x * RefT<WIDE>::STACK_ENTRY;
   // what a pop would return, read before the arithmetic so that its latency hides there
   const uint32_t below = tv.sp - LEVEL;
-  const uint32_t top = (uint32_t)*(const stack_t*)(lds + below);
+  const uint32_t top = stack_load<WIDE>(lds, below);
   R b[12];
   uint32_t c0, c1;
   load_node<WIDE>(sc, tv.cur, b, c0, c1);
@@ -544,7 +571,7 @@ __device__ __forceinline__ void node_step(const Scene& sc, const Ray<R>& ray, Tr
   const bool swp = tn1 < tn0;                         // meaningful when both are hit
   const uint32_t farc = swp ? c0 : c1;
   const uint32_t nearc = both ? (swp ? c1 : c0) : (h0 ? c0 : c1);
-  *(stack_t*)(lds + tv.sp) = (stack_t)farc;  // kept only if the address moves past it
+  stack_store<WIDE>(lds, tv.sp, farc);  // kept only if the address moves past it
   tv.cur = none ? top : nearc;
   tv.sp = both ? tv.sp + LEVEL : (none ? below : tv.sp);
 }
@@ -994,7 +1021,7 @@ enum : uint32_t { ST_LIVE = 0, ST_DEAD = 2, ST_DONE = 3 };
 // LDS of a render workgroup: [scene image (on-chip store only)][traversal stacks]
 // [per-wave tile sums]  (a lane pushes at most one entry per level of inner nodes above it)
 __host__ __device__ inline uint32_t stack_bytes(uint32_t threads, uint32_t depth, uint32_t wide) {
-  return (threads * (wide ? 4u : 2u) * (depth + 2u) + 15u) & ~15u;  // REF_EMPTY below, one slot above the deepest push
+  return (threads * (wide ? 3u : 2u) * (depth + 2u) + 15u) & ~15u;  // REF_EMPTY below, one slot above the deepest push
 }
 __host__ __device__ inline uint32_t image_bytes_in_lds(const SceneLayout& L) { return L.wide ? 0u : L.total_bytes; }
 constexpr uint32_t TILE_PIXELS = TILE_W * TILE_H;       // 64 = one wave
@@ -1017,7 +1044,6 @@ template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
 __device__ __forceinline__ void render_body(const RenderArgs& A) {
   extern __shared__ __align__(16) uint8_t lds[];
   typedef RefT<WIDE> RF;
-  typedef typename RF::stack_t stack_t;
   const uint32_t BT = blockDim.x;  // <= M<R>::BT, a multiple of 64
   Scene sc;
   sc.L = A.L;
@@ -1030,8 +1056,8 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
     lds_image = A.L.total_bytes;
   }
   // the lane's stack: level 0 (holds REF_EMPTY) and level 1, as byte offsets into lds
-  const uint32_t stack_level0 = lds_image + threadIdx.x * (uint32_t)sizeof(stack_t);
-  const uint32_t stack_level1 = stack_level0 + BT * (uint32_t)sizeof(stack_t);
+  const uint32_t stack_level0 = lds_image + threadIdx.x * 2u;
+  const uint32_t stack_level1 = stack_level0 + BT * RF::STACK_ENTRY;
   const uint32_t lane = threadIdx.x & 63u;
   unsigned long long* tile_acc = (unsigned long long*)(lds + lds_image + stack_bytes(BT, A.L.depth, WIDE ? 1u : 0u) +
                                                        (threadIdx.x >> 6) * TILE_ACC_BYTES);
@@ -1066,7 +1092,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
   ray.a = ray.inv_a = ray.oo = (R)0;
   trav_begin<R, WIDE>(tv, stack_level1);
   tv.cur = RF::EMPTY;
-  *(stack_t*)(lds + stack_level0) = (stack_t)RF::EMPTY;
+  stack_store<WIDE>(lds, stack_level0, RF::EMPTY);
 
   // adds the wave's tile sums to the frame and clears them
   auto flush_tile = [&]() {
@@ -1307,11 +1333,21 @@ render_kernel_lean(RenderArgs A, CamDev<float> cam) {
   render_body<float, false, FEAT, false>(A);
 }
 
+// The same for the HBM store: held to 96 scalar registers, a SIMD holds seven waves of it
+// instead of the six of the 103-106-register kernel, and with three-byte stack entries seven
+// 256-thread workgroups fit a CU's LDS up to 20 levels of hierarchy (100k triangles 9.72 ->
+// 9.94, a million 6.57 -> 7.48 G samples/s; the seventh group of the 106-register kernel was
+// accepted by the launch and never resident).
+template <uint32_t FEAT>
+__global__ void __launch_bounds__(M<float>::BT) __attribute__((amdgpu_waves_per_eu(7), amdgpu_num_sgpr(96)))
+render_kernel_lean_wide(RenderArgs A, CamDev<float> cam) {
+  render_body<float, false, FEAT, true>(A);
+}
+
 // world.hit(camera ray through the pixel centre, 0.001, +inf) for every pixel.
 template <typename R, bool WIDE>
 __global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, CamDev<R> cam) {
   extern __shared__ __align__(16) uint8_t lds[];
-  typedef typename RefT<WIDE>::stack_t stack_t;
   const uint32_t BT = blockDim.x;
   Scene sc;
   sc.L = A.L;
@@ -1323,8 +1359,8 @@ __global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, Cam
     sc.base = lds;
     lds_image = A.L.total_bytes;
   }
-  const uint32_t stack_level0 = lds_image + threadIdx.x * (uint32_t)sizeof(stack_t);
-  *(stack_t*)(lds + stack_level0) = (stack_t)RefT<WIDE>::EMPTY;
+  const uint32_t stack_level0 = lds_image + threadIdx.x * 2u;
+  stack_store<WIDE>(lds, stack_level0, RefT<WIDE>::EMPTY);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t tiles_x = (uint32_t)(A.W + TILE_W - 1) / TILE_W;
   const uint32_t tiles_y = (uint32_t)(A.H + TILE_H - 1) / TILE_H;
@@ -1344,7 +1380,7 @@ __global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, Cam
   camera_ray<R, RenderArgs>(ra, &cam, ray, px, py, no_rnd, 0.f, 0.f);  // jitter off: pixel centre, lens closed
   ray_setup<R>(ray);
   Trav<R> tv;
-  trace_closest<R, WIDE>(sc, ray, tv, lds, stack_level0 + BT * (uint32_t)sizeof(stack_t), (R)0.001);
+  trace_closest<R, WIDE>(sc, ray, tv, lds, stack_level0 + BT * RefT<WIDE>::STACK_ENTRY, (R)0.001);
 
   R* t_out = (R*)A.t;
   R* n_out = (R*)A.normal;
@@ -1436,7 +1472,6 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6)))
 wf_trace_kernel(WfArgs A) {
   extern __shared__ __align__(16) uint8_t lds[];
   typedef RefT<WIDE> RF;
-  typedef typename RF::stack_t stack_t;
   const uint32_t BT = blockDim.x;
   Scene sc;
   sc.L = A.L;
@@ -1448,9 +1483,9 @@ wf_trace_kernel(WfArgs A) {
     sc.base = lds;
     lds_image = A.L.total_bytes;
   }
-  const uint32_t stack_level0 = lds_image + threadIdx.x * (uint32_t)sizeof(stack_t);
-  const uint32_t stack_level1 = stack_level0 + BT * (uint32_t)sizeof(stack_t);
-  *(stack_t*)(lds + stack_level0) = (stack_t)RF::EMPTY;
+  const uint32_t stack_level0 = lds_image + threadIdx.x * 2u;
+  const uint32_t stack_level1 = stack_level0 + BT * RF::STACK_ENTRY;
+  stack_store<WIDE>(lds, stack_level0, RF::EMPTY);
   const uint32_t lane = threadIdx.x & 63u;
   const float t_min = 0.001f;
   const int REFILL = A.refill;  // idle lanes that trigger a refill
@@ -1684,13 +1719,17 @@ const RenderKernel32 k32[2][2][5] = {{HT_FEAT_ROW(float, false, false), HT_FEAT_
 const RenderKernel64 k64[2][2][5] = {{HT_FEAT_ROW(double, false, false), HT_FEAT_ROW(double, true, false)},
                                      {HT_FEAT_ROW(double, false, true), HT_FEAT_ROW(double, true, true)}};
 #undef HT_FEAT_ROW
-// KFEAT_LEAN: the fp32 on-chip production kernels held to 80 scalar registers
+// KFEAT_LEAN: the fp32 production kernels with plain textures held to 80 (on-chip store) or 96
+// (HBM store) scalar registers
 bool lean_variant(int precision, bool counters, uint32_t feat, bool wide) {
-  return (feat & KFEAT_LEAN) != 0u && precision == 0 && !counters && !wide && (feat & 3u) == 0u;
+  return (feat & KFEAT_LEAN) != 0u && precision == 0 && !counters && (feat & 3u) == 0u;
 }
-RenderKernel32 lean_kernel(uint32_t feat) { return (feat & FEAT_TRIS) ? render_kernel_lean<FEAT_TRIS> : render_kernel_lean<0>; }
+RenderKernel32 lean_kernel(uint32_t feat, bool wide) {
+  if (wide) return (feat & FEAT_TRIS) ? render_kernel_lean_wide<FEAT_TRIS> : render_kernel_lean_wide<0>;
+  return (feat & FEAT_TRIS) ? render_kernel_lean<FEAT_TRIS> : render_kernel_lean<0>;
+}
 const void* render_kernel_ptr(int precision, bool counters, uint32_t feat, bool wide) {
-  if (lean_variant(precision, counters, feat, wide)) return reinterpret_cast<const void*>(lean_kernel(feat));
+  if (lean_variant(precision, counters, feat, wide)) return reinterpret_cast<const void*>(lean_kernel(feat, wide));
   return precision == 0 ? reinterpret_cast<const void*>(k32[wide ? 1 : 0][counters ? 1 : 0][feat_index(feat)])
                         : reinterpret_cast<const void*>(k64[wide ? 1 : 0][counters ? 1 : 0][feat_index(feat)]);
 }
@@ -1702,7 +1741,11 @@ const void* render_kernel_ptr(int precision, bool counters, uint32_t feat, bool 
 constexpr uint32_t LDS_LIMIT_BYTES = 160u * 1024u;
 
 int render_max_waves_per_cu(int precision, bool counters, uint32_t feat, bool wide) {
-  return lean_variant(precision, counters, feat, wide) ? 32 : 28;
+  // by scalar registers (a wave's own, rounded up to 16, plus 16 the hardware keeps per wave, out
+  // of 800 per SIMD): <= 80: eight waves per SIMD; <= 96: seven; the 103-106 of the HBM store's
+  // plain kernels: six
+  if (lean_variant(precision, counters, feat, wide)) return wide ? 28 : 32;
+  return wide ? 24 : 28;
 }
 bool render_has_lean_variant(int precision, bool counters, uint32_t feat, bool wide) {
   return lean_variant(precision, counters, feat | KFEAT_LEAN, wide);
@@ -1728,7 +1771,7 @@ hipError_t launch_render(int precision, bool counters, uint32_t feat, const Rend
                          int grid_blocks, int threads, uint32_t lds_bytes, hipStream_t stream) {
   const int w = a.L.wide ? 1 : 0;
   if (lean_variant(precision, counters, feat, a.L.wide != 0u)) {
-    hipLaunchKernelGGL(lean_kernel(feat), dim3(grid_blocks), dim3(threads), lds_bytes, stream, a,
+    hipLaunchKernelGGL(lean_kernel(feat, a.L.wide != 0u), dim3(grid_blocks), dim3(threads), lds_bytes, stream, a,
                        *static_cast<const CamDev<float>*>(cam));
   } else if (precision == 0) {
     hipLaunchKernelGGL(k32[w][counters ? 1 : 0][feat_index(feat)], dim3(grid_blocks), dim3(threads), lds_bytes, stream,

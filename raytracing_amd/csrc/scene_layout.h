@@ -23,7 +23,10 @@ namespace ht {
 //   on-chip store (16 bits)                   HBM store (32 bits)
 //   inner node : index (< 0x8000)             index (< 0x80000000)
 //   leaf       : 0x8000 | kind << 12 | i      0x80000000 | kind << 28 | i
-//   empty      : 0xFFFF                       0xFFFFFFFF
+//   empty      : 0xFFFF                       0xF00FFFFF
+// (a wide reference has 24 significant bits: 31-28 and 19-0; an inner index is below 2^20
+// because a scene holds at most 2^20 primitives.  The traversal stack of the HBM store keeps
+// them as three bytes, RefT<true>::STACK_ENTRY.)
 // (i = index into the kind's array)
 enum : uint32_t {
   REF_LEAF = 0x8000u,
@@ -31,18 +34,18 @@ enum : uint32_t {
   REF_KIND_SHIFT = 12,
   REF_INDEX_MASK = 0x0FFFu,
   WREF_LEAF = 0x80000000u,
-  WREF_EMPTY = 0xFFFFFFFFu,
+  WREF_EMPTY = 0xF00FFFFFu,  // leaf bit, kind 7, index 0xFFFFF: 24 significant bits like every wide reference
   WREF_KIND_SHIFT = 28,
   WREF_INDEX_MASK = 0x0FFFFFFFu,
 };
 template <bool WIDE> struct RefT;
 template <> struct RefT<false> {
-  typedef uint16_t stack_t;
+  static constexpr uint32_t STACK_ENTRY = 2;  // bytes of a traversal-stack entry
   static constexpr uint32_t LEAF = REF_LEAF, EMPTY = REF_EMPTY, KIND_SHIFT = REF_KIND_SHIFT,
                             INDEX_MASK = REF_INDEX_MASK;
 };
 template <> struct RefT<true> {
-  typedef uint32_t stack_t;
+  static constexpr uint32_t STACK_ENTRY = 3;
   static constexpr uint32_t LEAF = WREF_LEAF, EMPTY = WREF_EMPTY, KIND_SHIFT = WREF_KIND_SHIFT,
                             INDEX_MASK = WREF_INDEX_MASK;
 };
