@@ -186,11 +186,11 @@ int launch_shape(ht_scene* s, int prec, bool counters, LaunchShape& out) {
     const uint32_t base_feat = s->feat | (L.tree_kinds == TREE_TRIANGLES ? KFEAT_TRIS : 0u);
     LaunchShape best;
     const int forced = g_block_threads.load();
-    // The variants held to 80 / 96 scalar registers run 1-3 % slower at equal occupancy (they
-    // keep some scalars in vector lanes) and are the only ones a CU holds 32 / 28 waves of: they
-    // are taken when that buys a larger shape (dragon: 1024 x 2 instead of 768 x 2, +5 %; Cornell
-    // box: 256 x 8 instead of 256 x 7, +6 %; HBM store: 256 x 7 instead of 256 x 6 or 5), not
-    // otherwise (random.json: 768 x 2 either way).
+    // The production kernels are compiled to 96 scalar registers (seven waves per SIMD); the
+    // on-chip ones with plain textures also to 80 (eight waves), 1-3 % slower at equal
+    // occupancy because more scalars live in vector lanes.  That variant is taken when it buys
+    // a larger shape (dragon: 1024 x 2 instead of 768 x 2, +5 %; Cornell box: 256 x 8 instead of
+    // 256 x 7), not otherwise (random.json: 768 x 2 either way).
     for (int lean = 0; lean <= (render_has_lean_variant(prec, counters, base_feat, L.wide != 0u) ? 1 : 0); ++lean) {
       const uint32_t kfeat = base_feat | (lean ? KFEAT_LEAN : 0u);
       for (int t = 256; t <= (int)max_block_threads(prec); t += 128) {

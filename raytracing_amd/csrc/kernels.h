@@ -106,15 +106,15 @@ uint32_t max_block_threads(int precision);
 // texture features a kernel variant is built for
 constexpr uint32_t KFEAT_PERLIN = 1u, KFEAT_IMAGE = 2u;
 constexpr uint32_t KFEAT_TRIS = 4u;  // the hierarchy holds triangles only (used when no texture bit is set)
-constexpr uint32_t KFEAT_LEAN = 8u;  // the variant held to 80 (on chip) / 96 (HBM store) scalar registers: fp32, plain textures
+constexpr uint32_t KFEAT_LEAN = 8u;  // the variant held to 80 scalar registers, eight waves per SIMD: fp32, on-chip store, plain textures
 
 // Number of workgroups of `threads` threads per CU the device can hold for this
 // kernel variant and LDS size (0: does not fit).
 int render_blocks_per_cu(int precision, bool counters, uint32_t feat, bool wide, int threads,
                          uint32_t lds_bytes);
 
-// Waves of that kernel variant a CU really holds, by its scalar registers (whatever the
-// occupancy query says): 32 up to 80 of them, 28 up to 96, 24 beyond.
+// Waves of that kernel variant a CU really holds, by the scalar registers it is compiled to
+// (whatever the occupancy query says): 32 up to 80 of them, 28 up to 96, 24 beyond.
 int render_max_waves_per_cu(int precision, bool counters, uint32_t feat, bool wide);
 // whether `feat | KFEAT_LEAN` names a kernel of its own for this precision / store
 bool render_has_lean_variant(int precision, bool counters, uint32_t feat, bool wide);

@@ -1034,11 +1034,10 @@ constexpr uint32_t TILE_ACC_BYTES = TILE_PIXELS * 3u * 8u;
 // the unit runs out the wave moves on to the next one at once while the
 // stragglers of the old unit are still in flight.
 // Waves per SIMD the register allocator must leave room for: the plain fp32 variants
-// are held to 80 VGPRs, so that 24 waves fit a CU next to the scene image; the on-chip variant
-// with image textures needs 74 and is held to the 72 of seven waves (two registers spilled:
-// scene.json 34.0 -> 35.2, checker.json 25.9 -> 26.6 G samples/s).
+// are held to 80 VGPRs, so that 24 waves fit a CU next to the scene image.  (The variants
+// that production launches go through render_kernel_7 / render_kernel_8 below.)
 template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
-struct MinWaves { static constexpr int value = (sizeof(R) == 4 && !CNT) ? ((FEAT & 3u) == 0u ? 6 : ((FEAT & 3u) == 3u ? 4 : ((FEAT & 3u) == 2u && !WIDE ? 7 : 5))) : 1; };
+struct MinWaves { static constexpr int value = (sizeof(R) == 4 && !CNT) ? ((FEAT & 3u) == 0u ? 6 : ((FEAT & 3u) == 3u ? 4 : 5)) : 1; };
 
 template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
 __device__ __forceinline__ void render_body(const RenderArgs& A) {
@@ -1317,31 +1316,34 @@ render_kernel(RenderArgs A, CamDev<R> cam) {
   render_body<R, CNT, FEAT, WIDE>(A);
 }
 
-// The production kernels of the on-chip store with plain textures, held to 80 scalar
-// registers.  A SIMD admits eight waves of a kernel only up to 80 of them (measured: at 86
-// and at 96, which the register file's 800 would seem to allow eight times, the eighth wave
-// never becomes resident; shapes of 512 x 4 and 256 x 8 ran at the rate of 512 x 3 and
-// 256 x 7).  The compiler keeps ~11 rarely used scalars in lanes of a vector register
-// instead, which costs 1-2 % at equal occupancy and buys the eighth wave: a second 1024-thread workgroup per
-// CU for scenes whose image leaves room for it, 256 x 8 for scenes without a hierarchy.
-// (The attribute takes a literal only, hence a kernel of its own and not a case of the
-// template above; the textured variants and the HBM store are short of vector registers
-// first and gain nothing.)
-template <uint32_t FEAT>
-__global__ void __launch_bounds__(M<float>::BT) __attribute__((amdgpu_waves_per_eu(6), amdgpu_num_sgpr(80)))
-render_kernel_lean(RenderArgs A, CamDev<float> cam) {
-  render_body<float, false, FEAT, false>(A);
-}
-
-// The same for the HBM store: held to 96 scalar registers, a SIMD holds seven waves of it
-// instead of the six of the 103-106-register kernel, and with three-byte stack entries seven
-// 256-thread workgroups fit a CU's LDS up to 20 levels of hierarchy (100k triangles 9.72 ->
-// 9.94, a million 6.57 -> 7.48 G samples/s; the seventh group of the 106-register kernel was
-// accepted by the launch and never resident).
-template <uint32_t FEAT>
+// Scalar registers decide how many waves of a kernel a SIMD really holds: a wave's own count,
+// rounded up to 16, plus 16 that the hardware keeps per wave, out of 800 per SIMD.  Up to 80:
+// eight waves; up to 96: seven; up to 112: six.  The occupancy query does not know (it answers
+// eight for all of these kernels), and a workgroup launched beyond the real limit is accepted
+// and never becomes resident: shapes of 256 x 8 and 256 x 7 ran at exactly the rate of 256 x 6
+// while the kernels used 98-106 scalar registers.  The compiler left to itself uses 96-106
+// here, so the production kernels are compiled to a stated budget (the attribute takes a
+// literal only, hence kernels of their own and not cases of the template above; the body is
+// the same function).  Scalars over the budget live in lanes of a vector register.
+//
+// Seven waves per SIMD, 96 scalar registers (0-10 of them in lanes) and at most 72 vector
+// registers: the fp32 production kernels of both stores with plain textures, and the
+// on-chip one with image textures (which needs 74 vector registers: two spilled; scene.json
+// 34.0 -> 35.2 G samples/s against six waves).  In the HBM store this is what makes the
+// seventh 256-thread workgroup real that the three-byte stack entries make room for.
+template <uint32_t FEAT, bool WIDE>
 __global__ void __launch_bounds__(M<float>::BT) __attribute__((amdgpu_waves_per_eu(7), amdgpu_num_sgpr(96)))
-render_kernel_lean_wide(RenderArgs A, CamDev<float> cam) {
-  render_body<float, false, FEAT, true>(A);
+render_kernel_7(RenderArgs A, CamDev<float> cam) {
+  render_body<float, false, FEAT, WIDE>(A);
+}
+// Eight waves per SIMD, 80 scalar registers (about eleven in lanes: 1-3 % slower at equal
+// occupancy): on-chip store, plain textures.  Taken where 32 waves fit a CU: a second
+// 1024-thread workgroup for scenes whose image leaves room for it (dragon), 256 x 8 for
+// scenes without a hierarchy (Cornell box).
+template <uint32_t FEAT>
+__global__ void __launch_bounds__(M<float>::BT) __attribute__((amdgpu_waves_per_eu(8), amdgpu_num_sgpr(80)))
+render_kernel_8(RenderArgs A, CamDev<float> cam) {
+  render_body<float, false, FEAT, false>(A);
 }
 
 // world.hit(camera ray through the pixel centre, 0.001, +inf) for every pixel.
@@ -1719,17 +1721,26 @@ const RenderKernel32 k32[2][2][5] = {{HT_FEAT_ROW(float, false, false), HT_FEAT_
 const RenderKernel64 k64[2][2][5] = {{HT_FEAT_ROW(double, false, false), HT_FEAT_ROW(double, true, false)},
                                      {HT_FEAT_ROW(double, false, true), HT_FEAT_ROW(double, true, true)}};
 #undef HT_FEAT_ROW
-// KFEAT_LEAN: the fp32 production kernels with plain textures held to 80 (on-chip store) or 96
-// (HBM store) scalar registers
-bool lean_variant(int precision, bool counters, uint32_t feat, bool wide) {
-  return (feat & KFEAT_LEAN) != 0u && precision == 0 && !counters && (feat & 3u) == 0u;
+// Which kernel a (precision, counters build, features, store) runs:
+//   8: render_kernel_8, asked for with KFEAT_LEAN: fp32, on-chip store, plain textures
+//   7: render_kernel_7: fp32, plain textures in either store, image textures on chip
+//   0: the generic template (counters builds, fp64, Perlin: six waves per SIMD or fewer anyway)
+int kernel_tier(int precision, bool counters, uint32_t feat, bool wide) {
+  if (precision != 0 || counters) return 0;
+  const uint32_t tex = feat & 3u;
+  if (tex == 0u) return ((feat & KFEAT_LEAN) && !wide) ? 8 : 7;
+  return (tex == 2u && !wide) ? 7 : 0;
 }
-RenderKernel32 lean_kernel(uint32_t feat, bool wide) {
-  if (wide) return (feat & FEAT_TRIS) ? render_kernel_lean_wide<FEAT_TRIS> : render_kernel_lean_wide<0>;
-  return (feat & FEAT_TRIS) ? render_kernel_lean<FEAT_TRIS> : render_kernel_lean<0>;
+RenderKernel32 tier_kernel(int tier, uint32_t feat, bool wide) {
+  const bool tris = (feat & FEAT_TRIS) != 0u;
+  if (tier == 8) return tris ? render_kernel_8<FEAT_TRIS> : render_kernel_8<0>;
+  if ((feat & 3u) == 2u) return render_kernel_7<2u, false>;
+  if (wide) return tris ? render_kernel_7<FEAT_TRIS, true> : render_kernel_7<0, true>;
+  return tris ? render_kernel_7<FEAT_TRIS, false> : render_kernel_7<0, false>;
 }
 const void* render_kernel_ptr(int precision, bool counters, uint32_t feat, bool wide) {
-  if (lean_variant(precision, counters, feat, wide)) return reinterpret_cast<const void*>(lean_kernel(feat, wide));
+  const int tier = kernel_tier(precision, counters, feat, wide);
+  if (tier) return reinterpret_cast<const void*>(tier_kernel(tier, feat, wide));
   return precision == 0 ? reinterpret_cast<const void*>(k32[wide ? 1 : 0][counters ? 1 : 0][feat_index(feat)])
                         : reinterpret_cast<const void*>(k64[wide ? 1 : 0][counters ? 1 : 0][feat_index(feat)]);
 }
@@ -1741,14 +1752,11 @@ const void* render_kernel_ptr(int precision, bool counters, uint32_t feat, bool 
 constexpr uint32_t LDS_LIMIT_BYTES = 160u * 1024u;
 
 int render_max_waves_per_cu(int precision, bool counters, uint32_t feat, bool wide) {
-  // by scalar registers (a wave's own, rounded up to 16, plus 16 the hardware keeps per wave, out
-  // of 800 per SIMD): <= 80: eight waves per SIMD; <= 96: seven; the 103-106 of the HBM store's
-  // plain kernels: six
-  if (lean_variant(precision, counters, feat, wide)) return wide ? 28 : 32;
-  return wide ? 24 : 28;
+  const int tier = kernel_tier(precision, counters, feat, wide);
+  return tier == 8 ? 32 : (tier == 7 ? 28 : 24);
 }
 bool render_has_lean_variant(int precision, bool counters, uint32_t feat, bool wide) {
-  return lean_variant(precision, counters, feat | KFEAT_LEAN, wide);
+  return kernel_tier(precision, counters, feat | KFEAT_LEAN, wide) == 8;
 }
 
 int render_blocks_per_cu(int precision, bool counters, uint32_t feat, bool wide, int threads,
@@ -1770,8 +1778,9 @@ int render_blocks_per_cu(int precision, bool counters, uint32_t feat, bool wide,
 hipError_t launch_render(int precision, bool counters, uint32_t feat, const RenderArgs& a, const void* cam,
                          int grid_blocks, int threads, uint32_t lds_bytes, hipStream_t stream) {
   const int w = a.L.wide ? 1 : 0;
-  if (lean_variant(precision, counters, feat, a.L.wide != 0u)) {
-    hipLaunchKernelGGL(lean_kernel(feat, a.L.wide != 0u), dim3(grid_blocks), dim3(threads), lds_bytes, stream, a,
+  const int tier = kernel_tier(precision, counters, feat, a.L.wide != 0u);
+  if (tier) {
+    hipLaunchKernelGGL(tier_kernel(tier, feat, a.L.wide != 0u), dim3(grid_blocks), dim3(threads), lds_bytes, stream, a,
                        *static_cast<const CamDev<float>*>(cam));
   } else if (precision == 0) {
     hipLaunchKernelGGL(k32[w][counters ? 1 : 0][feat_index(feat)], dim3(grid_blocks), dim3(threads), lds_bytes, stream,
