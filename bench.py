@@ -266,10 +266,10 @@ def main():
                 "frac": achieved / FP32_VALU_PEAK_TFLOPS,
                 "traffic": traffic,
                 "traffic_note": traffic_note,
-                # on-chip scenes with plain textures whose image leaves room for 32 waves per CU run
-                # the 80-scalar-register variant (render_kernel_lean), the others render_kernel
-                "kernel": "render_kernel_lean<FEAT> (80 scalar registers, 32 waves per CU) or render_kernel<float,false,FEAT,WIDE>: "
-                          "the variant the library picks for the scene; the rocprofv3 trace names it",
+                # the library picks the kernel per scene: render_kernel_8 (80 scalar registers, eight
+                # waves per SIMD) where 32 waves fit a CU, else render_kernel_7 (96, seven waves)
+                "kernel": "render_kernel_8<FEAT> or render_kernel_7<FEAT,WIDE>, whichever the library picks for the scene; "
+                          "the rocprofv3 trace names it",
                 "flops_per_sample": flops_per_sample,
                 "kernel_ms_per_launch": ksec / max(launches, 1) * 1e3,
                 "kernel_timing": kernel_timing,
