@@ -52,12 +52,14 @@ def test_struct_sizes_match_the_header(tmp_path):
 
 def test_options_need_no_device(ht):
     for name in ("wait_threshold", "max_blocks_per_cu", "default_batch", "chunk", "block_threads", "node_den",
-                 "wait_ratio_num", "wait_ratio_den", "force_hbm_scene", "chunk_tail"):
-        rc = ht.load().ht_set_option(name.encode(), 0 if name in ("block_threads", "force_hbm_scene") else 8)
+                 "wait_ratio_num", "wait_ratio_den", "force_hbm_scene", "chunk_tail", "max_waves_per_cu", "gpu_bvh",
+                 "wavefront", "wavefront_paths", "wavefront_refill"):
+        rc = ht.load().ht_set_option(name.encode(), 0 if name in ("block_threads", "force_hbm_scene", "gpu_bvh", "wavefront") else 8)
         assert rc == 0, name
     # back to the defaults the library starts with
     for name, v in (("wait_threshold", 40), ("max_blocks_per_cu", 8), ("default_batch", 1024), ("chunk", 0), ("chunk_tail", 4),
-                    ("block_threads", 0), ("node_den", 2), ("wait_ratio_num", 1000), ("wait_ratio_den", 1)):
+                    ("block_threads", 0), ("node_den", 2), ("wait_ratio_num", 1000), ("wait_ratio_den", 1),
+                    ("max_waves_per_cu", 0), ("wavefront_paths", 1 << 24), ("wavefront_refill", 32)):
         ht.set_option(name, v)
     with pytest.raises(ht.HipTraceError) as e:
         ht.set_option("no_such_option", 1)
