@@ -189,8 +189,8 @@ int launch_shape(ht_scene* s, int prec, bool counters, LaunchShape& out) {
     // The production kernels are compiled to 96 scalar registers (seven waves per SIMD); the
     // on-chip ones with plain textures also to 80 (eight waves), 1-3 % slower at equal
     // occupancy because more scalars live in vector lanes.  That variant is taken when it buys
-    // a larger shape (dragon: 1024 x 2 instead of 768 x 2, +5 %; Cornell box: 256 x 8 instead of
-    // 256 x 7), not otherwise (random.json: 768 x 2 either way).
+    // a larger shape (dragon: 1024 x 2 instead of 768 x 2, +5 %; scenes without an LDS image:
+    // 256 x 8 instead of 256 x 7, within 1 %), not otherwise (random.json: 768 x 2 either way).
     for (int lean = 0; lean <= (render_has_lean_variant(prec, counters, base_feat, L.wide != 0u) ? 1 : 0); ++lean) {
       const uint32_t kfeat = base_feat | (lean ? KFEAT_LEAN : 0u);
       for (int t = 256; t <= (int)max_block_threads(prec); t += 128) {
