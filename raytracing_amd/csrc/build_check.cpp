@@ -298,6 +298,16 @@ int main(int argc, char** argv) {
     CHECK(L->total_bytes == blob.size() && blob.size() % 16 == 0, "image size");
     CHECK(L->n_nodes == hs.nodes.size() && L->depth == (uint32_t)hs.depth, "layout counts");
     CHECK(!force_hbm || L->wide, "forced HBM store not taken");
+    if (L->wide) {
+      // a wide reference must survive the three-byte form the HBM store's traversal stack keeps:
+      // bits 31-28 and 19-0 only, and never the empty reference
+      for (size_t i = 0; i < hs.nodes.size(); ++i)
+        for (int c = 0; c < 2; ++c) {
+          const uint32_t r = hs.nodes[i].child[c];
+          const uint32_t packed = (r & 0xFFFFFu) | ((r >> 8) & 0xF00000u);
+          CHECK(((packed & 0xFFFFFu) | ((packed & 0xF00000u) << 8)) == r && r != WREF_EMPTY, "node %zu child %d: %08x does not fit 24 bits", i, c, r);
+        }
+    }
     if (!L->wide) {
       CHECK(hs.depth <= STACK_MAX_DEPTH && hs.sph.size() <= MAX_PER_KIND && hs.tri.size() <= MAX_PER_KIND, "on-chip limits");
       const uint32_t stride = L == &hs.layout32 ? 64u : 112u, co = L == &hs.layout32 ? 48u : 96u;
