@@ -152,3 +152,24 @@ def test_large_mesh_full_size_sums_do_not_depend_on_the_split(dev, mesh20k):
         np.testing.assert_array_equal(a["rgb"], b["rgb"])
         assert a["rgb"].min() >= 0 and np.isfinite(a["rgb"]).all()
         assert a["stats"]["samples"] == W * H * 16
+
+
+def test_six_hundred_thousand_triangles_first_hit(dev, oracle_mod, flat_scene):
+    """Primitive and node indices beyond 2^19: every bit of the 20-bit index field of a wide
+    reference (and of its three-byte form on the traversal stack) is in use."""
+    cam, _, _ = flat_scene("dragon")
+    flat = flatten(mesh_world(400, 750))
+    assert flat.n_prims > (1 << 19) + 70000
+    W, H = 160, 90
+    o = oracle_mod.OracleScene(flat, bvh_seed=1).first_hit(cam, W, H)
+    with dev.Scene(flat, device=0) as s:
+        info = s.info()
+        g = s.first_hit(cam, W, H, precision=A.HT_PRECISION_FP64)
+        a = s.render(cam, 192, 108, 4, seed=3, batch=4)
+        b = s.render(cam, 192, 108, 4, seed=3, batch=1)
+    assert info["hbm_store_fp32"] == 1 and info["n_nodes"] > 300000
+    assert np.array_equal(g["prim_id"], o["prim_id"])
+    assert (o["prim_id"] > (1 << 19)).any()  # triangles from the top of the index range are in view
+    hit = o["prim_id"] >= 0
+    np.testing.assert_allclose(g["t64"][hit], o["t"][hit], rtol=1e-9)
+    np.testing.assert_array_equal(a["rgb"], b["rgb"])
