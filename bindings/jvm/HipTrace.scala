@@ -55,7 +55,7 @@ object HipTrace {
     val CAMERA_FOCUS_DISTANCE = 96L
     val CAMERA_BACKGROUND = 104L
     // struct ht_render_params
-    val PARAMS_SIZE = 48L
+    val PARAMS_SIZE = 64L
     val PARAMS_WIDTH = 0L
     val PARAMS_HEIGHT = 4L
     val PARAMS_SAMPLES = 8L
@@ -67,6 +67,10 @@ object HipTrace {
     val PARAMS_SEED = 32L
     val PARAMS_DEVICE = 40L
     val PARAMS_COLLECT_COUNTERS = 44L
+    val PARAMS_TILE_FIRST = 48L      // tile sharding: 0 / 0 = every tile of the frame
+    val PARAMS_TILE_STRIDE = 52L
+    val PARAMS_SHARD_MODE = 56L      // ht_render_sharded only
+    val PARAMS_RESERVED = 60L
     // type tags and strides
     val PRIM_STRIDE = 9   // doubles per primitive
     val TEX_STRIDE = 4    // doubles per texture

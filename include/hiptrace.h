@@ -145,15 +145,34 @@ typedef struct ht_render_params {
   uint64_t seed;          /* Philox key                                             */
   int32_t device;         /* -1, or the ordinal the scene lives on (checked)       */
   int32_t collect_counters; /* 1: run the instrumented kernel and fill ht_stats.n_* */
+  /* Tile sharding (main.scala:79-81 loops over independent pixels).  The frame's 8x8-pixel
+   * tiles are numbered row-major from the bottom-left corner (tiles per row = ceil(width/8));
+   * the call renders only the tiles tile_first, tile_first + tile_stride, ... and leaves the
+   * other pixels' sums untouched.  tile_stride 0 or 1: every tile (tile_first must be 0).
+   * A node that shards by tiles gives rank g of G the pair (g, G) and all samples. */
+  int32_t tile_first;
+  int32_t tile_stride;
+  int32_t shard_mode;     /* ht_render_sharded only: HT_SHARD_SAMPLES or HT_SHARD_TILES   */
+  int32_t reserved;       /* 0 */
 } ht_render_params;
+
+/* How ht_render_sharded cuts a frame between its scene handles. */
+enum {
+  HT_SHARD_SAMPLES = 0, /* handle k renders samples [k*S/n, (k+1)*S/n) of every pixel; the partial sums
+                           (24 bytes per pixel) are added across devices                             */
+  HT_SHARD_TILES = 1    /* handle k renders every sample of the tiles k, k+n, k+2n, ...; nothing is
+                           added, each device resolves its own tiles and the first one gathers the
+                           pictures (4 + 12 bytes per pixel, 1/n of the frame per device)             */
+};
 
 /* Work counters (per call; n_* only when collect_counters = 1). */
 typedef struct ht_stats {
   double seconds_total;   /* wall time of the call                                 */
   double seconds_kernel;  /* device time of the path-tracing launches (HIP events) */
-  int64_t samples;        /* width*height*samples                                   */
+  int64_t samples;        /* camera paths traced: the call's pixels (all of the frame, or those of
+                             its own tiles) x samples_per_pixel                     */
   int32_t launches;       /* path-tracing kernel launches                           */
-  int32_t reserved;
+  int32_t samples_per_pixel; /* samples per pixel the call launched (fewer than asked for when cancelled) */
   int64_t n_rays;         /* rays traced (camera + scattered)                       */
   int64_t n_box;          /* ray / AABB slab tests                                  */
   int64_t n_sphere;       /* ray / sphere tests                                     */
@@ -172,6 +191,11 @@ typedef struct ht_stats {
   int32_t lds_bytes;      /*   LDS bytes per workgroup (scene image + stacks + tile sums)   */
   int32_t n_cu;           /*   compute units of the device                                  */
   double shader_clock_mhz; /* in-kernel clock: s_memtime ticks per 100 MHz s_memrealtime tick */
+  int32_t batch;          /* samples per pixel of a full launch as the library planned it   */
+  int32_t kernel_sgprs;   /* scalar-register budget the chosen kernel is compiled to (80 / 96; 0: not capped) */
+  char kernel[64];        /* the path-tracing kernel the library chose for this scene, as a profiler
+                             shows it: "render_kernel_8<4u>", "render_kernel_7<0u, true>",
+                             "render_kernel<float, false, 1u, false>", or "wavefront"           */
 } ht_stats;
 
 typedef struct ht_scene ht_scene; /* opaque */
@@ -243,7 +267,10 @@ int ht_render_accumulate(ht_scene* scene, const ht_camera* camera,
  * (S = params->samples, starting at params->sample_offset) into a sum buffer on
  * its own device; the partial sums are then copied to scenes[0]'s device
  * (device-to-device, over xGMI between GPUs of one node) and added there, and the
- * frame is resolved as in ht_render.  The samples of a pixel are a plain sum in the
+ * frame is resolved as in ht_render (params->shard_mode = HT_SHARD_SAMPLES, the default).
+ * With HT_SHARD_TILES handle k renders every sample of the tiles k, k + n, ... instead,
+ * resolves them on its own device, and only the pictures travel to scenes[0]'s device.
+ * The samples of a pixel are a plain sum in the
  * reference (main.scala:87-91), so any split gives the picture ht_render gives for
  * the same seed, bit for bit.  The handles must hold the same scene; they may live
  * on different devices (one per GPU of the node: the single-process form of spp
@@ -265,6 +292,27 @@ int ht_resolve(ht_scene* scene, const int64_t* accum_dev, int32_t width, int32_t
 int ht_resolve_device(ht_scene* scene, const int64_t* accum_dev, int32_t width, int32_t height,
                       int64_t total_samples, float* rgb_linear_dev, uint32_t* rgb_packed_dev,
                       void* stream);
+
+/* Tile sharding, the pictures.  A shard that rendered the tiles (tile_first, tile_stride) of a
+ * frame resolves them into TILE BUFFERS on its own device: owned tile k (tile number
+ * tile_first + k * tile_stride) fills pixels [64 k, 64 k + 64) of the buffer, pixel
+ * q = 8 * (row within the tile, bottom row first) + column; pixels outside the frame are 0.
+ *   packed_tiles_dev  0x00RRGGBB codes (Vec3.toRGB, Vec3.scala:82-84), one uint32 per pixel
+ *   mean_tiles_dev    mean linear radiance, three floats per pixel
+ * Either may be NULL.  ht_shard_tile_pixels(width, height, n_shards) is the number of pixels a
+ * shard's buffer must hold (64 * ceil(tiles / n_shards), the same for every shard). */
+int64_t ht_shard_tile_pixels(int32_t width, int32_t height, int32_t n_shards);
+int ht_resolve_tiles_device(ht_scene* scene, const int64_t* accum_dev, int32_t width, int32_t height,
+                            int64_t total_samples, int32_t tile_first, int32_t tile_stride,
+                            float* mean_tiles_dev, uint32_t* packed_tiles_dev, void* stream);
+/* The frame from the tile buffers of all n_shards shards, gathered into one DEVICE array each
+ * (shard g's buffer starts g * ht_shard_tile_pixels(..) pixels in: the layout an all-gather or a
+ * gather to the root leaves).  Outputs as in ht_resolve_device: rgb_linear_dev row 0 = bottom,
+ * rgb_packed_dev row 0 = top (the flip of img.setRGB(i, H-j-1, ..), main.scala:93); a NULL input
+ * skips its output. */
+int ht_assemble_tiles_device(ht_scene* scene, int32_t width, int32_t height, int32_t n_shards,
+                             const float* mean_tiles_all_dev, const uint32_t* packed_tiles_all_dev,
+                             float* rgb_linear_dev, uint32_t* rgb_packed_dev, void* stream);
 
 /* A frame: a device accumulation buffer owned by the library, for callers that
  * cannot allocate device memory themselves (a JVM host) and for progressive

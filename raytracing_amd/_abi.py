@@ -13,6 +13,7 @@ HT_TEX_STRIDE = 4
 HT_PERLIN_POINTS = 256
 HT_PRECISION_FP32, HT_PRECISION_FP64 = 0, 1
 HT_NOALLOC_MAX_PIXELS = 1 << 21
+HT_SHARD_SAMPLES, HT_SHARD_TILES = 0, 1
 
 _pi32 = C.POINTER(C.c_int32)
 _pi64 = C.POINTER(C.c_int64)
@@ -73,6 +74,10 @@ class ht_render_params(C.Structure):
         ("seed", C.c_uint64),
         ("device", C.c_int32),
         ("collect_counters", C.c_int32),
+        ("tile_first", C.c_int32),
+        ("tile_stride", C.c_int32),
+        ("shard_mode", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -82,7 +87,7 @@ class ht_stats(C.Structure):
         ("seconds_kernel", C.c_double),
         ("samples", C.c_int64),
         ("launches", C.c_int32),
-        ("reserved", C.c_int32),
+        ("samples_per_pixel", C.c_int32),
         ("n_rays", C.c_int64),
         ("n_box", C.c_int64),
         ("n_sphere", C.c_int64),
@@ -103,13 +108,18 @@ class ht_stats(C.Structure):
         ("lds_bytes", C.c_int32),
         ("n_cu", C.c_int32),
         ("shader_clock_mhz", C.c_double),
+        ("batch", C.c_int32),
+        ("kernel_sgprs", C.c_int32),
+        ("kernel", C.c_char * 64),
     ]
 
     def as_dict(self):
         d = {}
         for name, _ in self._fields_:
             v = getattr(self, name)
-            d[name] = list(v) if hasattr(v, "__len__") else v
+            if isinstance(v, bytes):
+                v = v.decode("ascii", "replace")
+            d[name] = list(v) if hasattr(v, "__len__") and not isinstance(v, str) else v
         return d
 
 
@@ -139,6 +149,9 @@ EXPORTS = [
     "ht_render_accumulate", "ht_render_sharded",
     "ht_resolve",
     "ht_resolve_device",
+    "ht_shard_tile_pixels",
+    "ht_resolve_tiles_device",
+    "ht_assemble_tiles_device",
     "ht_frame_create",
     "ht_frame_destroy",
     "ht_frame_clear",

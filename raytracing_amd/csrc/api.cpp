@@ -50,9 +50,22 @@ struct ht_scene {
   uint32_t feat = 0;  // KFEAT_* texture kinds present in the scene
   std::mutex shape_mutex;
   LaunchShape shape[2][2];  // [precision][counters]
-  // workspace of the wavefront variant (path state between the stage kernels), grown on demand
+  // workspace of the wavefront variant (path state between the stage kernels), grown on demand;
+  // wavefront renders of one handle run one at a time (wf_mutex)
   uint8_t* d_wf = nullptr;
   size_t wf_bytes = 0;
+  std::mutex wf_mutex;
+  // Device buffers of the host-buffer entry points (ht_render, ht_resolve, ht_frame_read), kept
+  // between calls and grown on demand: a frame's sums, its means and its packed picture.  A call
+  // holds host_mutex while it uses them (one host-buffer call per handle at a time).
+  std::mutex host_mutex;
+  int64_t* d_host_accum = nullptr;
+  float* d_host_mean = nullptr;
+  uint32_t* d_host_packed = nullptr;
+  size_t host_accum_pixels = 0, host_mean_pixels = 0, host_packed_pixels = 0;
+  // HIP events of finished calls, reused by later ones
+  std::mutex event_mutex;
+  std::vector<hipEvent_t> timing_events, plain_events;
 };
 
 struct ht_frame {
@@ -168,7 +181,60 @@ int check_params(const ht_scene* s, const ht_render_params* p) {
     return fail(HT_E_INVALID, "unknown precision %d", p->precision);
   if (s && p->device >= 0 && p->device != s->device)
     return fail(HT_E_INVALID, "scene lives on device %d, params ask for %d", s->device, p->device);
+  if (p->tile_stride < 0 || p->tile_first < 0 || p->tile_first >= std::max(1, p->tile_stride))
+    return fail(HT_E_INVALID, "tile_first must be in [0, max(tile_stride, 1)) (got first %d, stride %d)", p->tile_first,
+                p->tile_stride);
   return HT_OK;
+}
+
+// Pixels of the frame inside the tiles first, first + stride, ... (edge tiles hold fewer than 64)
+int64_t owned_pixels(int32_t W, int32_t H, int32_t first, int32_t stride) {
+  if (stride <= 1) return (int64_t)W * H;
+  const int32_t tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
+  int64_t n = 0;
+  for (int64_t t = first; t < (int64_t)tiles_x * tiles_y; t += stride) {
+    const int32_t x0 = (int32_t)(t % tiles_x) * TILE_W, y0 = (int32_t)(t / tiles_x) * TILE_H;
+    n += (int64_t)std::min(TILE_W, W - x0) * std::min(TILE_H, H - y0);
+  }
+  return n;
+}
+
+// Events are taken from the scene's pool and handed back, so that a call creates none once
+// the pool is warm.  Timing events only for callers that want statistics.
+struct EventLease {
+  ht_scene* s;
+  bool timing;
+  hipEvent_t ev = nullptr;
+  EventLease(ht_scene* s_, bool timing_) : s(s_), timing(timing_) {}
+  hipError_t acquire() {
+    {
+      std::lock_guard<std::mutex> lock(s->event_mutex);
+      std::vector<hipEvent_t>& pool = timing ? s->timing_events : s->plain_events;
+      if (!pool.empty()) { ev = pool.back(); pool.pop_back(); return hipSuccess; }
+    }
+    return timing ? hipEventCreate(&ev) : hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  }
+  ~EventLease() {
+    if (!ev) return;
+    try {
+      std::lock_guard<std::mutex> lock(s->event_mutex);
+      (timing ? s->timing_events : s->plain_events).push_back(ev);
+    } catch (...) {
+      (void)hipEventDestroy(ev);
+    }
+  }
+};
+
+// Grows one of the scene's cached device buffers to `pixels` pixels of `elem` bytes.
+template <typename T>
+hipError_t grow(T*& buf, size_t& have, size_t pixels, size_t elem) {
+  if (have >= pixels && buf) return hipSuccess;
+  if (buf) (void)hipFree(buf);
+  buf = nullptr;
+  have = 0;
+  const hipError_t e = hipMalloc((void**)&buf, pixels * elem);
+  if (e == hipSuccess) have = pixels;
+  return e;
 }
 
 // Workgroup size and count of the render kernel for this scene: the combination that keeps
@@ -282,6 +348,8 @@ int make_plan(ht_scene* s, const ht_camera* cam, const ht_render_params* p, int6
   a.wait_ratio_den = g_wait_den.load();
   a.inv_w1 = 1.0f / (float)(p->width - 1);
   a.inv_h1 = 1.0f / (float)(p->height - 1);
+  a.tile_stride = std::max(1, p->tile_stride);
+  a.tile_first = p->tile_first;
 
   int batch = p->batch > 0 ? p->batch : g_default_batch.load();
   // the work queue of one launch is indexed with 32 bits: tiles x sample chunks
@@ -297,7 +365,9 @@ hipError_t enqueue_launch(const RenderPlan& pl, uint32_t* queue_head, int first,
   a.sample_first = first;
   a.sample_count = count;
   a.tile_counter = queue_head;
-  hipError_t e = hipMemsetAsync(queue_head, 0, QUEUE_SLOT_BYTES, stream);
+  // the queue head starts behind the units the waves take without asking: one per wave
+  const int n_waves = pl.grid * (pl.shape.threads / 64);
+  hipError_t e = hipMemsetD32Async((hipDeviceptr_t)queue_head, n_waves, QUEUE_SLOT_BYTES / 4, stream);
   if (e == hipSuccess)
     e = launch_render(pl.prec, pl.counters, pl.kfeat, a, pl.camp, pl.grid, pl.shape.threads, pl.shape.lds, stream);
   return e;
@@ -309,6 +379,10 @@ hipError_t enqueue_launch(const RenderPlan& pl, uint32_t* queue_head, int first,
 // that survive a shade stage is read back each round, so the call synchronises with `stream`.
 int render_wavefront(ht_scene* s, const RenderPlan& pl, int first, int count, hipStream_t stream) {
   const RenderArgs& ra = pl.a;
+  if (ra.tile_stride > 1) return fail(HT_E_INVALID, "the wavefront variant renders whole frames only (tile_stride > 1)");
+  // the workspace below belongs to the handle: one wavefront render of it at a time (every
+  // round synchronises with the stream anyway)
+  std::lock_guard<std::mutex> wf_lock(s->wf_mutex);
   const uint64_t WH = (uint64_t)ra.W * (uint64_t)ra.H;
   // a sub-launch holds at most 2^28 items: their contributions (12 bytes each, 3.2 GB at most)
   // are kept until the reduce, and every sub-launch pays the drain of its last long paths
@@ -410,51 +484,53 @@ int render_accumulate_impl(ht_scene* s, const ht_camera* cam, const ht_render_pa
   if (rc != HT_OK) return rc;
   if (pl.counters) HIP_TRY(hipMemsetAsync(s->d_counters, 0, NUM_COUNTERS * sizeof(unsigned long long), stream));
 
-  hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_batch[2] = {nullptr, nullptr};
-  auto cleanup = [&]() {
-    if (ev_start) (void)hipEventDestroy(ev_start);
-    if (ev_stop) (void)hipEventDestroy(ev_stop);
-    if (ev_batch[0]) (void)hipEventDestroy(ev_batch[0]);
-    if (ev_batch[1]) (void)hipEventDestroy(ev_batch[1]);
-  };
+  // Timing events only for a caller that wants statistics; the two pacing events only when
+  // the call makes more than two launches (they keep at most two batches in flight so that a
+  // cancel request is seen soon).  A plain one-launch call creates and records none.
+  const int n_launches = (p->samples + pl.batch - 1) / pl.batch;
+  EventLease l_start(s, true), l_stop(s, true), l_batch0(s, false), l_batch1(s, false);
   {
-    hipError_t ce = hipEventCreate(&ev_start);
-    if (ce == hipSuccess) ce = hipEventCreate(&ev_stop);
-    if (ce == hipSuccess) ce = hipEventCreateWithFlags(&ev_batch[0], hipEventDisableTiming);
-    if (ce == hipSuccess) ce = hipEventCreateWithFlags(&ev_batch[1], hipEventDisableTiming);
+    hipError_t ce = hipSuccess;
+    if (stats) {
+      ce = l_start.acquire();
+      if (ce == hipSuccess) ce = l_stop.acquire();
+    }
+    if (ce == hipSuccess && n_launches > 2) {
+      ce = l_batch0.acquire();
+      if (ce == hipSuccess) ce = l_batch1.acquire();
+    }
     if (ce != hipSuccess) {
       (void)hipGetLastError();
-      cleanup();
       return fail(HT_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(ce));
     }
   }
-
+  const hipEvent_t ev_start = l_start.ev, ev_stop = l_stop.ev;
+  const hipEvent_t ev_batch[2] = {l_batch0.ev, l_batch1.ev};
   int launches = 0, done = 0;
   bool cancelled = false;
   const bool wavefront = g_wavefront.load() != 0 && pl.prec == HT_PRECISION_FP32 && !pl.counters;
-  hipError_t e = hipEventRecord(ev_start, stream);
+  hipError_t e = ev_start ? hipEventRecord(ev_start, stream) : hipSuccess;
   while (e == hipSuccess && done < p->samples) {
     // keep at most two batches in flight so that a cancel request is seen soon
-    if (launches >= 2) e = hipEventSynchronize(ev_batch[launches & 1]);
+    if (launches >= 2 && ev_batch[0]) e = hipEventSynchronize(ev_batch[launches & 1]);
     if (e != hipSuccess) break;
     if (s->cancel.exchange(0)) { cancelled = true; break; }
     const int count = std::min(pl.batch, p->samples - done);
     if (wavefront) {
       const int wrc = render_wavefront(s, pl, p->sample_offset + done, count, stream);
-      if (wrc != HT_OK) { cleanup(); return wrc; }
+      if (wrc != HT_OK) return wrc;
     } else {
       e = enqueue_launch(pl, next_queue_head(s), p->sample_offset + done, count, stream);
     }
-    if (e == hipSuccess) e = hipEventRecord(ev_batch[launches & 1], stream);
+    if (e == hipSuccess && ev_batch[0]) e = hipEventRecord(ev_batch[launches & 1], stream);
     if (e == hipSuccess) {
       done += count;
       launches++;
     }
   }
-  if (e == hipSuccess) e = hipEventRecord(ev_stop, stream);
+  if (e == hipSuccess && ev_stop) e = hipEventRecord(ev_stop, stream);
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    cleanup();
     return fail(HT_E_HIP, "render launch failed: %s", hipGetErrorString(e));
   }
   if (stats) {
@@ -488,7 +564,6 @@ int render_accumulate_impl(ht_scene* s, const ht_camera* cam, const ht_render_pa
     }
     if (e != hipSuccess) {
       (void)hipGetLastError();
-      cleanup();
       return fail(HT_E_HIP, "render failed on the device: %s", hipGetErrorString(e));
     }
     stats->block_threads = pl.shape.threads;
@@ -497,11 +572,19 @@ int render_accumulate_impl(ht_scene* s, const ht_camera* cam, const ht_render_pa
     stats->n_cu = s->n_cu;
     stats->seconds_kernel = ms * 1e-3;
     stats->launches = launches;
-    stats->samples = (int64_t)p->width * p->height * done;  // what was launched, also when cancelled
+    stats->batch = pl.batch;
+    if (wavefront) {
+      snprintf(stats->kernel, sizeof stats->kernel, "wavefront");
+    } else {
+      stats->kernel_sgprs = render_kernel_name(pl.prec, pl.counters, pl.kfeat, pl.a.L.wide != 0u, stats->kernel,
+                                               sizeof stats->kernel);
+    }
+    // what was launched, also when cancelled: the pixels of the call's own tiles x samples
+    stats->samples = owned_pixels(p->width, p->height, pl.a.tile_first, pl.a.tile_stride) * done;
+    stats->samples_per_pixel = done;
     stats->seconds_total =
         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
-  cleanup();
   if (cancelled) return fail(HT_E_CANCELLED, "render cancelled after %d batches (%d samples per pixel)", launches, done);
   return HT_OK;
 }
@@ -553,6 +636,11 @@ void ht_scene_destroy(ht_scene* s) {
     if (s->d_queue_heads) (void)hipFree(s->d_queue_heads);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->d_wf) (void)hipFree(s->d_wf);
+    if (s->d_host_accum) (void)hipFree(s->d_host_accum);
+    if (s->d_host_mean) (void)hipFree(s->d_host_mean);
+    if (s->d_host_packed) (void)hipFree(s->d_host_packed);
+    for (hipEvent_t ev : s->timing_events) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : s->plain_events) (void)hipEventDestroy(ev);
   }
   delete s;
 }
@@ -698,36 +786,75 @@ int ht_resolve_device(ht_scene* s, const int64_t* accum_dev, int32_t W, int32_t 
   return HT_OK;
 }
 
-int ht_resolve(ht_scene* s, const int64_t* accum_dev, int32_t W, int32_t H, int64_t total_samples,
-               float* rgb_linear, uint32_t* rgb_packed, void* stream_v) {
-  if (!s || !accum_dev) return fail(HT_E_INVALID, "NULL argument");
-  if (W < 1 || H < 1 || total_samples < 1) return fail(HT_E_INVALID, "bad resolve dimensions");
-  hipStream_t stream = (hipStream_t)stream_v;
-  DeviceGuard g(s->device);
-  if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
+namespace {
+// ht_resolve with the scene's host_mutex held by the caller: mean / toRGB / flip into the
+// scene's cached device pictures, then the copies into the caller's host buffers.
+int resolve_to_host_locked(ht_scene* s, const int64_t* accum_dev, int32_t W, int32_t H, int64_t total_samples,
+                           float* rgb_linear, uint32_t* rgb_packed, hipStream_t stream) {
   const size_t n = (size_t)W * H;
-  float* d_mean = nullptr;
-  uint32_t* d_packed = nullptr;
-  if (rgb_linear) HIP_TRY(hipMalloc((void**)&d_mean, n * 3 * sizeof(float)));
-  if (rgb_packed) {
-    hipError_t e = hipMalloc((void**)&d_packed, n * sizeof(uint32_t));
-    if (e != hipSuccess) {
-      if (d_mean) (void)hipFree(d_mean);
-      return fail(HT_E_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
-    }
-  }
+  if (rgb_linear) HIP_TRY(grow(s->d_host_mean, s->host_mean_pixels, n, 3 * sizeof(float)));
+  if (rgb_packed) HIP_TRY(grow(s->d_host_packed, s->host_packed_pixels, n, sizeof(uint32_t)));
+  float* d_mean = rgb_linear ? s->d_host_mean : nullptr;
+  uint32_t* d_packed = rgb_packed ? s->d_host_packed : nullptr;
   hipError_t e = launch_resolve((const long long*)accum_dev, W, H, 1.0 / (double)total_samples, d_mean, d_packed, stream);
-  if (e == hipSuccess && rgb_linear)
-    e = hipMemcpyAsync(rgb_linear, d_mean, n * 3 * sizeof(float), hipMemcpyDeviceToHost, stream);
+  // the packed picture first: it is what renderFrame's caller shows (main.scala:93)
   if (e == hipSuccess && rgb_packed)
     e = hipMemcpyAsync(rgb_packed, d_packed, n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess && rgb_linear)
+    e = hipMemcpyAsync(rgb_linear, d_mean, n * 3 * sizeof(float), hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
-  if (d_mean) (void)hipFree(d_mean);
-  if (d_packed) (void)hipFree(d_packed);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     return fail(HT_E_HIP, "resolve failed: %s", hipGetErrorString(e));
   }
+  return HT_OK;
+}
+}  // namespace
+
+int ht_resolve(ht_scene* s, const int64_t* accum_dev, int32_t W, int32_t H, int64_t total_samples,
+               float* rgb_linear, uint32_t* rgb_packed, void* stream_v) {
+  if (!s || !accum_dev) return fail(HT_E_INVALID, "NULL argument");
+  if (W < 1 || H < 1 || total_samples < 1) return fail(HT_E_INVALID, "bad resolve dimensions");
+  HT_API_TRY
+  DeviceGuard g(s->device);
+  if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
+  std::lock_guard<std::mutex> lock(s->host_mutex);
+  return resolve_to_host_locked(s, accum_dev, W, H, total_samples, rgb_linear, rgb_packed, (hipStream_t)stream_v);
+  HT_API_CATCH
+}
+
+int64_t ht_shard_tile_pixels(int32_t W, int32_t H, int32_t n_shards) {
+  if (W < 1 || H < 1 || n_shards < 1) return 0;
+  const int64_t tiles = (int64_t)tiles_in_frame(W, H);
+  return ((tiles + n_shards - 1) / n_shards) * (int64_t)(TILE_W * TILE_H);
+}
+
+int ht_resolve_tiles_device(ht_scene* s, const int64_t* accum_dev, int32_t W, int32_t H, int64_t total_samples,
+                            int32_t tile_first, int32_t tile_stride, float* mean_tiles_dev,
+                            uint32_t* packed_tiles_dev, void* stream_v) {
+  if (!s || !accum_dev) return fail(HT_E_INVALID, "NULL argument");
+  if (W < 1 || H < 1 || total_samples < 1) return fail(HT_E_INVALID, "bad resolve dimensions");
+  if ((int64_t)W * H > (int64_t)1 << 30) return fail(HT_E_INVALID, "image too large");
+  if (tile_stride < 0 || tile_first < 0 || tile_first >= std::max(1, tile_stride))
+    return fail(HT_E_INVALID, "tile_first must be in [0, max(tile_stride, 1))");
+  DeviceGuard g(s->device);
+  if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
+  HIP_TRY(launch_resolve_tiles((const long long*)accum_dev, W, H, 1.0 / (double)total_samples, (uint32_t)tile_first,
+                               (uint32_t)std::max(1, tile_stride), mean_tiles_dev, packed_tiles_dev,
+                               (hipStream_t)stream_v));
+  return HT_OK;
+}
+
+int ht_assemble_tiles_device(ht_scene* s, int32_t W, int32_t H, int32_t n_shards, const float* mean_tiles_all_dev,
+                             const uint32_t* packed_tiles_all_dev, float* rgb_linear_dev, uint32_t* rgb_packed_dev,
+                             void* stream_v) {
+  if (!s) return fail(HT_E_INVALID, "scene is NULL");
+  if (W < 1 || H < 1 || n_shards < 1) return fail(HT_E_INVALID, "bad assemble dimensions");
+  if ((int64_t)W * H > (int64_t)1 << 30) return fail(HT_E_INVALID, "image too large");
+  DeviceGuard g(s->device);
+  if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
+  HIP_TRY(launch_assemble_tiles(W, H, (uint32_t)n_shards, (size_t)ht_shard_tile_pixels(W, H, n_shards), mean_tiles_all_dev,
+                                packed_tiles_all_dev, rgb_linear_dev, rgb_packed_dev, (hipStream_t)stream_v));
   return HT_OK;
 }
 
@@ -743,18 +870,16 @@ int ht_render(ht_scene* s, const ht_camera* cam, const ht_render_params* p, floa
   DeviceGuard g(s->device);
   if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
   const size_t n = (size_t)p->width * p->height;
-  int64_t* d_accum = nullptr;
-  HIP_TRY(hipMalloc((void**)&d_accum, n * 3 * sizeof(int64_t)));
-  hipError_t e = hipMemsetAsync(d_accum, 0, n * 3 * sizeof(int64_t), nullptr);
-  if (e != hipSuccess) {
-    (void)hipFree(d_accum);
-    return fail(HT_E_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
-  }
+  // the sums live in the handle's cached buffer: no allocation once it has the frame's size
+  std::lock_guard<std::mutex> lock(s->host_mutex);
+  HIP_TRY(grow(s->d_host_accum, s->host_accum_pixels, n, 3 * sizeof(int64_t)));
+  int64_t* d_accum = s->d_host_accum;
+  HIP_TRY(hipMemsetAsync(d_accum, 0, n * 3 * sizeof(int64_t), nullptr));
   ht_stats st;
-  rc = render_accumulate_impl(s, cam, p, d_accum, nullptr, &st, true);
+  rc = render_accumulate_impl(s, cam, p, d_accum, nullptr, stats_out ? &st : nullptr, true);
+  // (a tile shard through this call resolves the whole frame: the tiles it did not render are black)
   if (rc == HT_OK)
-    rc = ht_resolve(s, d_accum, p->width, p->height, p->samples, rgb_linear, rgb_packed, nullptr);
-  (void)hipFree(d_accum);
+    rc = resolve_to_host_locked(s, d_accum, p->width, p->height, p->samples, rgb_linear, rgb_packed, nullptr);
   if (rc == HT_OK && stats_out) {
     *stats_out = st;
     stats_out->seconds_total =
@@ -800,6 +925,171 @@ int ht_render_noalloc(ht_scene* s, const ht_camera* cam, const ht_render_params*
   return HT_OK;
 }
 
+// ht_render_sharded with HT_SHARD_TILES: handle k renders every sample of the tiles k, k + n, ...
+// into a sum buffer on its own device and resolves them there into tile buffers (1/n of the
+// frame each); the tile buffers go to the first device (peer copies, all at once, each over its
+// own link), which puts the frame together.  No sums cross a link: 16 bytes per pixel of the
+// frame in all instead of 24 bytes per pixel per device.
+static int render_sharded_tiles(ht_scene* const* scenes, int32_t n, const ht_camera* cam, const ht_render_params* p,
+                                float* rgb_linear, uint32_t* rgb_packed, ht_stats* stats_out) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const int32_t W = p->width, H = p->height;
+  const size_t pixels = (size_t)W * H;
+  const size_t shard_px = (size_t)ht_shard_tile_pixels(W, H, n);
+  for (int k = 0; k < n; ++k) scenes[k]->cancel.store(0);  // requests older than this frame
+  struct Shard {
+    int64_t* d_accum = nullptr;
+    float* d_mean_tiles = nullptr;       // shards 1..n-1: this shard's tile buffers on its own device
+    uint32_t* d_packed_tiles = nullptr;
+    ht_render_params params;
+    ht_stats stats;
+    int rc = HT_OK;
+    std::string error;
+  };
+  std::vector<Shard> shards((size_t)n);
+  float* d_mean_all = nullptr;       // on the first device: every shard's tile buffers, shard g at g * shard_px
+  uint32_t* d_packed_all = nullptr;
+  auto release = [&]() {
+    for (int k = 0; k < n; ++k) {
+      DeviceGuard g(scenes[k]->device);
+      Shard& sh = shards[(size_t)k];
+      if (sh.d_accum) (void)hipFree(sh.d_accum);
+      if (k > 0 && sh.d_mean_tiles) (void)hipFree(sh.d_mean_tiles);
+      if (k > 0 && sh.d_packed_tiles) (void)hipFree(sh.d_packed_tiles);
+    }
+    DeviceGuard g(scenes[0]->device);
+    if (d_mean_all) (void)hipFree(d_mean_all);
+    if (d_packed_all) (void)hipFree(d_packed_all);
+  };
+  {
+    DeviceGuard g(scenes[0]->device);
+    hipError_t e = g.ok ? hipSuccess : hipErrorInvalidDevice;
+    if (e == hipSuccess && rgb_linear) e = hipMalloc((void**)&d_mean_all, shard_px * (size_t)n * 3 * sizeof(float));
+    if (e == hipSuccess && rgb_packed) e = hipMalloc((void**)&d_packed_all, shard_px * (size_t)n * sizeof(uint32_t));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      release();
+      return fail(HT_E_HIP, "allocation of the gathered tile buffers failed: %s", hipGetErrorString(e));
+    }
+  }
+  for (int k = 0; k < n; ++k) {
+    Shard& sh = shards[(size_t)k];
+    sh.params = *p;
+    sh.params.tile_first = k;
+    sh.params.tile_stride = n;
+    sh.params.device = -1;
+    memset(&sh.stats, 0, sizeof sh.stats);
+    DeviceGuard g(scenes[k]->device);
+    hipError_t e = g.ok ? hipMalloc((void**)&sh.d_accum, pixels * 3 * sizeof(int64_t)) : hipErrorInvalidDevice;
+    if (e == hipSuccess) e = hipMemset(sh.d_accum, 0, pixels * 3 * sizeof(int64_t));
+    if (k == 0) {  // the first shard resolves straight into its place in the gathered arrays
+      sh.d_mean_tiles = d_mean_all;
+      sh.d_packed_tiles = d_packed_all;
+    } else {
+      if (e == hipSuccess && rgb_linear) e = hipMalloc((void**)&sh.d_mean_tiles, shard_px * 3 * sizeof(float));
+      if (e == hipSuccess && rgb_packed) e = hipMalloc((void**)&sh.d_packed_tiles, shard_px * sizeof(uint32_t));
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      release();
+      return fail(HT_E_HIP, "shard %d: allocation failed: %s", k, hipGetErrorString(e));
+    }
+  }
+  // one host thread per shard: render, then resolve the shard's own tiles on its own device
+  {
+    std::vector<std::thread> workers;
+    for (int k = 0; k < n; ++k) {
+      Shard* sh = &shards[(size_t)k];
+      ht_scene* sc = scenes[k];
+      const int64_t total = p->samples;
+      workers.emplace_back([sh, sc, cam, W, H, total]() {
+        try {
+          sh->rc = render_accumulate_impl(sc, cam, &sh->params, sh->d_accum, nullptr, &sh->stats, false);
+          if (sh->rc == HT_OK)
+            sh->rc = ht_resolve_tiles_device(sc, sh->d_accum, W, H, total, sh->params.tile_first, sh->params.tile_stride,
+                                             sh->d_mean_tiles, sh->d_packed_tiles, nullptr);
+          if (sh->rc == HT_OK) {
+            DeviceGuard g(sc->device);
+            const hipError_t e = hipStreamSynchronize(nullptr);
+            if (e != hipSuccess) {
+              (void)hipGetLastError();
+              sh->rc = fail(HT_E_HIP, "resolve of the shard's tiles failed: %s", hipGetErrorString(e));
+            }
+          }
+          if (sh->rc != HT_OK) sh->error = ht_last_error();  // the message is per thread: carry it over
+        } catch (...) {
+          sh->rc = HT_E_INVALID;
+        }
+      });
+    }
+    for (auto& w : workers) w.join();
+  }
+  for (int k = 0; k < n; ++k)
+    if (shards[(size_t)k].rc != HT_OK) {
+      const int code = shards[(size_t)k].rc;
+      const std::string msg = shards[(size_t)k].error;
+      release();
+      return fail(code, "shard %d: %s", k, msg.c_str());
+    }
+  // gather: every other device sends its tile buffers to the first one, all at once
+  hipError_t e = hipSuccess;
+  for (int k = 1; k < n && e == hipSuccess; ++k) {
+    const int dk = scenes[k]->device, d0 = scenes[0]->device;
+    DeviceGuard g(dk);
+    if (dk != d0) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, dk, d0) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(d0, 0);
+      (void)hipGetLastError();
+    }
+    if (rgb_packed)
+      e = hipMemcpyPeerAsync(d_packed_all + (size_t)k * shard_px, d0, shards[(size_t)k].d_packed_tiles, dk,
+                             shard_px * sizeof(uint32_t), nullptr);
+    if (e == hipSuccess && rgb_linear)
+      e = hipMemcpyPeerAsync(d_mean_all + (size_t)k * shard_px * 3, d0, shards[(size_t)k].d_mean_tiles, dk,
+                             shard_px * 3 * sizeof(float), nullptr);
+  }
+  for (int k = 1; k < n; ++k) {
+    DeviceGuard g(scenes[k]->device);
+    const hipError_t se = hipStreamSynchronize(nullptr);
+    if (e == hipSuccess) e = se;
+  }
+  int rc = HT_OK;
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    rc = fail(HT_E_HIP, "gathering the shards' tiles failed: %s", hipGetErrorString(e));
+  } else {
+    ht_scene* s0 = scenes[0];
+    DeviceGuard g(s0->device);
+    std::lock_guard<std::mutex> lock(s0->host_mutex);
+    if (rgb_linear) e = grow(s0->d_host_mean, s0->host_mean_pixels, pixels, 3 * sizeof(float));
+    if (e == hipSuccess && rgb_packed) e = grow(s0->d_host_packed, s0->host_packed_pixels, pixels, sizeof(uint32_t));
+    if (e == hipSuccess)
+      e = launch_assemble_tiles(W, H, (uint32_t)n, shard_px, d_mean_all, d_packed_all, rgb_linear ? s0->d_host_mean : nullptr,
+                                rgb_packed ? s0->d_host_packed : nullptr, nullptr);
+    if (e == hipSuccess && rgb_packed)
+      e = hipMemcpyAsync(rgb_packed, s0->d_host_packed, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, nullptr);
+    if (e == hipSuccess && rgb_linear)
+      e = hipMemcpyAsync(rgb_linear, s0->d_host_mean, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      rc = fail(HT_E_HIP, "assembling the frame failed: %s", hipGetErrorString(e));
+    }
+  }
+  release();
+  if (rc == HT_OK && stats_out) {
+    *stats_out = shards[0].stats;
+    for (int k = 1; k < n; ++k) {
+      const ht_stats& st = shards[(size_t)k].stats;
+      stats_out->samples += st.samples;
+      stats_out->launches += st.launches;
+      stats_out->seconds_kernel = std::max(stats_out->seconds_kernel, st.seconds_kernel);
+    }
+    stats_out->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return rc;
+}
+
 int ht_render_sharded(ht_scene* const* scenes, int32_t n, const ht_camera* cam, const ht_render_params* p,
                       float* rgb_linear, uint32_t* rgb_packed, ht_stats* stats_out) {
   if (!scenes || !p) return fail(HT_E_INVALID, "NULL argument");
@@ -816,7 +1106,11 @@ int ht_render_sharded(ht_scene* const* scenes, int32_t n, const ht_camera* cam, 
   if (rc != HT_OK) return rc;
   rc = check_params(nullptr, p);
   if (rc != HT_OK) return rc;
+  if (p->shard_mode != HT_SHARD_SAMPLES && p->shard_mode != HT_SHARD_TILES)
+    return fail(HT_E_INVALID, "unknown shard_mode %d", p->shard_mode);
+  if (p->tile_stride > 1) return fail(HT_E_INVALID, "ht_render_sharded cuts the frame itself: tile_stride must be 0 or 1");
   HT_API_TRY
+  if (p->shard_mode == HT_SHARD_TILES && n > 1) return render_sharded_tiles(scenes, n, cam, p, rgb_linear, rgb_packed, stats_out);
   const auto t0 = std::chrono::steady_clock::now();
   const size_t words = (size_t)p->width * p->height * 3;
   const size_t bytes = words * sizeof(int64_t);
@@ -1020,7 +1314,7 @@ int ht_frame_accumulate(ht_frame* f, const ht_camera* cam, const ht_render_param
   rc = render_accumulate_impl(f->scene, cam, p, f->d_accum, nullptr, &st, true);
   if (rc == HT_OK || rc == HT_E_CANCELLED) {
     // a cancelled call still added the batches it had launched
-    f->samples += st.samples / ((int64_t)f->width * f->height);
+    f->samples += st.samples_per_pixel;
     if (stats_out) *stats_out = st;
   }
   return rc;

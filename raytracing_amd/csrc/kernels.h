@@ -24,7 +24,8 @@ struct RenderArgs {
   SceneLayout L;
   const uint32_t* texels;  // image texels, 0x00RRGGBB
   long long* accum;        // [H*W*3] radiance sums, signed 32.32 fixed point, row 0 = bottom
-  uint32_t* tile_counter;  // work-unit queue head, zeroed before every launch
+  uint32_t* tile_counter;  // work-unit queue head, set to the number of waves of the launch before it starts
+                           //   (wave w takes unit w first, then asks the counter)
   unsigned long long* counters;  // NUM_COUNTERS words, or nullptr
   int32_t W, H;
   int32_t sample_first;    // global index of the first sample of this launch
@@ -39,6 +40,8 @@ struct RenderArgs {
   int32_t node_den;        // node steps go on while inner lanes * node_den >= travelling lanes
   int32_t wait_ratio_num, wait_ratio_den;  // traversal also yields when waiting/travelling >= num/den
   float inv_w1, inv_h1;    // 1/(W-1), 1/(H-1) correctly rounded (jittered fp32 sample positions)
+  int32_t tile_first;      // this launch renders the 8x8 tiles tile_first, tile_first + tile_stride, ... of the
+  int32_t tile_stride;     //   frame (row-major tile numbers); 0 / 1: every tile
 };
 
 // ---- wavefront variant: the same paths as render_kernel, one kernel per stage ----------
@@ -116,6 +119,9 @@ int render_blocks_per_cu(int precision, bool counters, uint32_t feat, bool wide,
 // Waves of that kernel variant a CU really holds, by the scalar registers it is compiled to
 // (whatever the occupancy query says): 32 up to 80 of them, 28 up to 96, 24 beyond.
 int render_max_waves_per_cu(int precision, bool counters, uint32_t feat, bool wide);
+// name of the kernel a (precision, counters build, features, store) runs, as a profiler prints it
+// ("render_kernel_8<4u>"); returns the scalar-register budget it is compiled to (80, 96; 0: none)
+int render_kernel_name(int precision, bool counters, uint32_t feat, bool wide, char* out, size_t n);
 // whether `feat | KFEAT_LEAN` names a kernel of its own for this precision / store
 bool render_has_lean_variant(int precision, bool counters, uint32_t feat, bool wide);
 
@@ -144,5 +150,24 @@ hipError_t static_scratch(int device, void** out);
 // mean + Vec3.toRGB + row flip (Vec3.scala:82-84, main.scala:93)
 hipError_t launch_resolve(const long long* accum, int32_t W, int32_t H, double inv_samples,
                           float* rgb_mean, uint32_t* rgb_packed, hipStream_t stream);
+
+// Tile sharding.  The frame's 8x8 tiles are numbered row-major; shard g of n owns the tiles
+// g, g + n, g + 2n, ...  A shard's picture is kept compact: owned tile k (tile number
+// g + k n) occupies pixels [64 k, 64 k + 64) of a tile buffer, pixel q = (row within the tile,
+// bottom row first) * 8 + column; pixels beyond the frame's edge are zero.
+inline uint32_t tiles_in_frame(int32_t W, int32_t H) {
+  return (uint32_t)((W + TILE_W - 1) / TILE_W) * (uint32_t)((H + TILE_H - 1) / TILE_H);
+}
+inline uint32_t tiles_owned(uint32_t n_tiles, uint32_t first, uint32_t stride) {
+  return first < n_tiles ? (n_tiles - first + stride - 1u) / stride : 0u;
+}
+// mean and Vec3.toRGB code of the owned tiles' pixels, in tile order (no row flip yet)
+hipError_t launch_resolve_tiles(const long long* accum, int32_t W, int32_t H, double inv_samples, uint32_t tile_first,
+                                uint32_t tile_stride, float* mean_tiles, uint32_t* packed_tiles, hipStream_t stream);
+// the frame from the tile buffers of n shards (buffer g starts g * shard_pixels pixels into the arrays):
+// rgb_mean row 0 = bottom, rgb_packed row 0 = top (the row flip of main.scala:93)
+hipError_t launch_assemble_tiles(int32_t W, int32_t H, uint32_t n_shards, size_t shard_pixels, const float* mean_tiles,
+                                 const uint32_t* packed_tiles, float* rgb_mean, uint32_t* rgb_packed,
+                                 hipStream_t stream);
 
 }  // namespace ht

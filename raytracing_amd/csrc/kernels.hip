@@ -36,6 +36,8 @@
 //  the reference.
 #include <hip/hip_runtime.h>
 
+#include <stdio.h>
+
 #include <mutex>
 
 #include "../../include/hiptrace.h"
@@ -119,6 +121,9 @@ template <typename R> __device__ __forceinline__ V3<R> cross(V3<R> a, V3<R> b) {
   return mk<R>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 template <typename R, typename P> __device__ __forceinline__ V3<R> ld3(P p) { return mk<R>(p[0], p[1], p[2]); }
+// a fused multiply-add that is written out (where the compiler's own contraction is switched off)
+__device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 // ---------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011)
@@ -392,6 +397,37 @@ __device__ __forceinline__ bool sphere_solve(const Scene& sc, const Ray<R>& ray,
   return true;
 }
 
+// Offset of the ray's point of closest approach from a sphere's centre, l = (o - c) - q d with
+// q = (o - c).d / |d|^2, for shading.  |l| is of the size of the radius while o - c and q d are
+// of the size of the distance travelled, so the two roundings that matter (of o - c and of the
+// product q d) are carried along as error terms (TwoSum, TwoProduct by fused multiply-add):
+// the result is as good as the ray itself.  Plain fp32 leaves an error of ~1e-6 of the
+// distance, 1e-5 of a 0.2-radius sphere's normal at 20 units.  No contraction in here: the
+// error terms are differences of rounded values.
+template <typename R>
+__device__ __forceinline__ V3<R> closest_approach_offset(const Ray<R>& ray, V3<R> cen, R& q) {
+#pragma clang fp contract(off)
+  const R o[3] = {ray.o.x, ray.o.y, ray.o.z}, c[3] = {cen.x, cen.y, cen.z}, d[3] = {ray.d.x, ray.d.y, ray.d.z};
+  R oc[3], oce[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {  // o - c = oc + oce exactly
+    const R nb = -c[k];
+    oc[k] = o[k] + nb;
+    const R bp = oc[k] - o[k];
+    const R ap = oc[k] - bp;
+    oce[k] = (o[k] - ap) + (nb - bp);
+  }
+  q = (oc[0] * d[0] + oc[1] * d[1] + oc[2] * d[2]) * ray.inv_a;
+  R l[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {  // q d = p + pe exactly
+    const R p = q * d[k];
+    const R pe = fma_r(q, d[k], -p);
+    l[k] = (oc[k] - p) + (oce[k] - pe);
+  }
+  return mk<R>(l[0], l[1], l[2]);
+}
+
 template <typename R>
 struct RectGeom {
   R a0, a1, b0, b1, k;
@@ -642,15 +678,19 @@ __device__ __forceinline__ HitGeom<R> hit_geometry(const Scene& sc, const Ray<R>
       pc = h.p - mk<R>(s.x, s.y, s.z);
       rad = s.w;
     } else {
-      SphereSolve<R> ss;
-      sphere_solve<R>(sc, ray, KIND_SPHERE, h.idx, ss);
+      typename M<R>::R4 s = load_r4<R>(sc, sc.L.sph, h.idx);
+      const V3<R> cen = mk<R>(s.x, s.y, s.z);
+      rad = s.w;
+      R q;
+      const V3<R> l0 = closest_approach_offset<R>(ray, cen, q);
       // one re-orthogonalisation of l against d removes the along-ray error that the
       // rounding of the closest-approach parameter left in it
-      const V3<R> l = ss.l - (dot(ss.l, ray.d) * ray.inv_a) * ray.d;
-      const bool near_root = M<R>::fabs(t - ss.t1) <= M<R>::fabs(t - ss.t2);
-      pc = l + (near_root ? -ss.s : ss.s) * ray.d;
-      h.p = ss.cen + pc;
-      rad = ss.rad;
+      const V3<R> l = l0 - (dot(l0, ray.d) * ray.inv_a) * ray.d;
+      // half-chord from the same l, so that |pc| = radius; the accepted root is the near one
+      // when t lies before the point of closest approach (parameter -q)
+      const R hc = M<R>::sqrt(M<R>::fmax(rad * rad - dot(l, l), (R)0) * ray.inv_a);
+      pc = l + ((t + q <= (R)0) ? -hc : hc) * ray.d;
+      h.p = cen + pc;
     }
     h.n_out = M<R>::rcp(rad) * pc;
     h.meta = load_u32(sc, sc.L.meta_sph, h.idx);
@@ -705,8 +745,6 @@ __device__ __forceinline__ void hit_uv(const Scene& sc, const Ray<R>& ray, const
 // sine, and left to itself the compiler fuses them differently in every kernel the function
 // is inlined into, so the variants of the renderer would disagree in the last bit of a fifth
 // of a Perlin scene's sums.
-__device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-__device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <typename R>
 __device__ __forceinline__ R perlin_noise(const Scene& sc, uint32_t table, V3<R> p) {
 #pragma clang fp contract(off)
@@ -1158,7 +1196,9 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
         const auto* ca = kernarg_args();
         const uint32_t tiles_x = (uint32_t)(ca->W + TILE_W - 1) / TILE_W;
         const uint32_t tiles_y = (uint32_t)(ca->H + TILE_H - 1) / TILE_H;
-        const uint32_t n_tiles = tiles_x * tiles_y;
+        // tile sharding: this launch owns every tile_stride-th tile from tile_first on
+        const uint32_t t_first = (uint32_t)ca->tile_first, t_stride = (uint32_t)ca->tile_stride;
+        const uint32_t n_tiles = t_first < tiles_x * tiles_y ? (tiles_x * tiles_y - t_first + t_stride - 1u) / t_stride : 0u;
         // the last `chunk` samples of the launch are cut into units of `chunk_tail` samples:
         // the units still running when the queue runs dry decide how long the launch drags on
         const uint32_t chunk = (uint32_t)ca->chunk, chunk_tail = (uint32_t)ca->chunk_tail;
@@ -1167,8 +1207,11 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
         const uint32_t n_big = (s_big + chunk - 1u) / chunk;
         const uint32_t n_small = (s_total - s_big + chunk_tail - 1u) / chunk_tail;
         const uint32_t n_units = n_tiles * (n_big + n_small);
-        uint32_t unit = 0;
-        if (lane == 0) unit = atomicAdd(ca->tile_counter, 1u);
+        // A wave's first unit is its own number in the launch (the host starts the queue head at
+        // the number of waves): thousands of waves asking one counter at the same moment would
+        // be served one at a time.  Later units come from the counter.
+        uint32_t unit = blockIdx.x * (BT >> 6) + (threadIdx.x >> 6);
+        if (epoch != 0u && lane == 0) unit = atomicAdd(ca->tile_counter, 1u);
         // every lane is here (the loop's control is wave-uniform); read as a scalar, so that
         // the unit's state lives in scalar registers and the loop branches on scalars
         unit = __builtin_amdgcn_readfirstlane(unit);
@@ -1177,7 +1220,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
           epoch++;  // whatever is still in flight deposits to the frame directly
           continue;
         }
-        const uint32_t tile = unit % n_tiles, ck = unit / n_tiles;
+        const uint32_t ck = unit / n_tiles, tile = t_first + (unit - ck * n_tiles) * t_stride;
         tile_x0 = (tile % tiles_x) * TILE_W;
         tile_y0 = (tile / tiles_x) * TILE_H;
         uint32_t first, count;
@@ -1402,6 +1445,22 @@ __global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, Cam
   }
 }
 
+// Vec3.toRGB of one pixel's mean radiance (Vec3.scala:82-84): 255 * clamp(sqrt(x), 0, 0.999) truncated,
+// NaN -> 0, packed 0x00RRGGBB; also stores the three means when `mean` is given.
+__device__ __forceinline__ uint32_t resolve_pixel(const long long* __restrict__ sums, double inv_samples,
+                                                  float* __restrict__ mean) {
+  uint32_t code = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const double m = (double)sums[c] * (1.0 / 4294967296.0) * inv_samples;
+    if (mean) mean[c] = (float)m;
+    double g = ::sqrt(m);
+    g = ::fmin(::fmax(g, 0.0), 0.999);  // fmax(NaN, 0) = 0, the value NaN.toInt gives
+    code = (code << 8) | (uint32_t)(int)(255.0 * g);
+  }
+  return code;
+}
+
 // mean radiance from the 32.32 fixed-point sums, Vec3.toRGB (Vec3.scala:82-84:
 // 255 * clamp(sqrt(x), 0, 0.999), truncated; NaN -> 0) and the row flip of
 // img.setRGB(i, H-j-1, ..) (main.scala:93)
@@ -1411,16 +1470,51 @@ __global__ void resolve_kernel(const long long* __restrict__ accum, int32_t W, i
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (uint32_t)(W * H)) return;
   const uint32_t i = p % (uint32_t)W, j = p / (uint32_t)W;
-  uint32_t code = 0;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const double m = (double)accum[(size_t)p * 3u + c] * (1.0 / 4294967296.0) * inv_samples;
-    if (rgb_mean) rgb_mean[(size_t)p * 3u + c] = (float)m;
-    double g = ::sqrt(m);
-    g = ::fmin(::fmax(g, 0.0), 0.999);  // fmax(NaN, 0) = 0, the value NaN.toInt gives
-    code = (code << 8) | (uint32_t)(int)(255.0 * g);
-  }
+  const uint32_t code = resolve_pixel(accum + (size_t)p * 3u, inv_samples, rgb_mean ? rgb_mean + (size_t)p * 3u : nullptr);
   if (rgb_packed) rgb_packed[(size_t)((uint32_t)H - 1u - j) * (uint32_t)W + i] = code;
+}
+
+// The same for the tiles one shard owns (tile_first, tile_first + tile_stride, ...), written
+// compactly in tile order: thread = (owned tile k, pixel q of the tile).  No row flip here.
+__global__ void resolve_tiles_kernel(const long long* __restrict__ accum, int32_t W, int32_t H, double inv_samples,
+                                     uint32_t tile_first, uint32_t tile_stride, uint32_t n_owned,
+                                     float* __restrict__ mean_tiles, uint32_t* __restrict__ packed_tiles) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t k = g / TILE_PIXELS, q = g % TILE_PIXELS;
+  if (k >= n_owned) return;
+  const uint32_t tiles_x = (uint32_t)(W + TILE_W - 1) / TILE_W;
+  const uint32_t tile = tile_first + k * tile_stride;
+  const uint32_t px = (tile % tiles_x) * TILE_W + (q & 7u), py = (tile / tiles_x) * TILE_H + (q >> 3);
+  uint32_t code = 0;
+  float m[3] = {0.f, 0.f, 0.f};
+  if (px < (uint32_t)W && py < (uint32_t)H)
+    code = resolve_pixel(accum + ((size_t)py * (uint32_t)W + px) * 3u, inv_samples, m);
+  if (packed_tiles) packed_tiles[g] = code;
+  if (mean_tiles) {
+    mean_tiles[(size_t)g * 3u] = m[0];
+    mean_tiles[(size_t)g * 3u + 1u] = m[1];
+    mean_tiles[(size_t)g * 3u + 2u] = m[2];
+  }
+}
+
+// The frame from the shards' tile buffers: thread = pixel (i, j), j = 0 the bottom row.
+// Tile t belongs to shard t % n_shards and is that shard's tile number t / n_shards.
+__global__ void assemble_tiles_kernel(int32_t W, int32_t H, uint32_t n_shards, size_t shard_pixels,
+                                      const float* __restrict__ mean_tiles, const uint32_t* __restrict__ packed_tiles,
+                                      float* __restrict__ rgb_mean, uint32_t* __restrict__ rgb_packed) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (uint32_t)(W * H)) return;
+  const uint32_t i = p % (uint32_t)W, j = p / (uint32_t)W;
+  const uint32_t tiles_x = (uint32_t)(W + TILE_W - 1) / TILE_W;
+  const uint32_t tile = (j / TILE_H) * tiles_x + i / TILE_W;
+  const size_t src = (size_t)(tile % n_shards) * shard_pixels + (size_t)(tile / n_shards) * TILE_PIXELS +
+                     (j % TILE_H) * TILE_W + i % TILE_W;
+  if (rgb_packed && packed_tiles) rgb_packed[(size_t)((uint32_t)H - 1u - j) * (uint32_t)W + i] = packed_tiles[src];
+  if (rgb_mean && mean_tiles) {
+    rgb_mean[(size_t)p * 3u] = mean_tiles[src * 3u];
+    rgb_mean[(size_t)p * 3u + 1u] = mean_tiles[src * 3u + 1u];
+    rgb_mean[(size_t)p * 3u + 2u] = mean_tiles[src * 3u + 2u];
+  }
 }
 
 // dst += src: integer sums, so the order in which shards are combined does not matter
@@ -1755,6 +1849,25 @@ int render_max_waves_per_cu(int precision, bool counters, uint32_t feat, bool wi
   const int tier = kernel_tier(precision, counters, feat, wide);
   return tier == 8 ? 32 : (tier == 7 ? 28 : 24);
 }
+// The chosen kernel's name as a profiler prints it (without namespace and arguments); returns
+// the scalar-register budget it is compiled to (0: the generic template, not capped).
+int render_kernel_name(int precision, bool counters, uint32_t feat, bool wide, char* out, size_t n) {
+  const int tier = kernel_tier(precision, counters, feat, wide);
+  const unsigned f = (feat & 3u) == 0u && (feat & FEAT_TRIS) ? FEAT_TRIS : (feat & 3u);
+  if (tier == 8) {
+    snprintf(out, n, "render_kernel_8<%uu>", f);
+    return 80;
+  }
+  if (tier == 7) {
+    snprintf(out, n, "render_kernel_7<%uu, %s>", f, wide ? "true" : "false");
+    return 96;
+  }
+  // the generic table has the triangle-only variant for the fp32 production build only
+  const unsigned fg = (precision == 0 && !counters) ? f : (feat & 3u);
+  snprintf(out, n, "render_kernel<%s, %s, %uu, %s>", precision == 0 ? "float" : "double", counters ? "true" : "false", fg,
+           wide ? "true" : "false");
+  return 0;
+}
 bool render_has_lean_variant(int precision, bool counters, uint32_t feat, bool wide) {
   return kernel_tier(precision, counters, feat | KFEAT_LEAN, wide) == 8;
 }
@@ -1871,6 +1984,24 @@ hipError_t launch_accum_add_many(long long* dst, const long long* src, size_t n,
   if (n == 0 || count <= 0) return hipSuccess;
   hipLaunchKernelGGL(accum_add_many_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dst, src, n,
                      count);
+  return hipGetLastError();
+}
+
+hipError_t launch_resolve_tiles(const long long* accum, int32_t W, int32_t H, double inv_samples, uint32_t tile_first,
+                                uint32_t tile_stride, float* mean_tiles, uint32_t* packed_tiles, hipStream_t stream) {
+  const uint32_t n_owned = tiles_owned(tiles_in_frame(W, H), tile_first, tile_stride);
+  if (n_owned == 0u) return hipSuccess;
+  hipLaunchKernelGGL(resolve_tiles_kernel, dim3((n_owned * TILE_PIXELS + 255u) / 256u), dim3(256), 0, stream, accum, W, H,
+                     inv_samples, tile_first, tile_stride, n_owned, mean_tiles, packed_tiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_assemble_tiles(int32_t W, int32_t H, uint32_t n_shards, size_t shard_pixels, const float* mean_tiles,
+                                 const uint32_t* packed_tiles, float* rgb_mean, uint32_t* rgb_packed,
+                                 hipStream_t stream) {
+  const uint32_t n = (uint32_t)(W * H);
+  hipLaunchKernelGGL(assemble_tiles_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W, H, n_shards, shard_pixels,
+                     mean_tiles, packed_tiles, rgb_mean, rgb_packed);
   return hipGetLastError();
 }
 

@@ -1,11 +1,20 @@
 """Sharding of one frame over the GPUs of a node.
 
 Every camera path is independent (the reference's pixel value is a plain sum
-over samples, jvm/src/main/scala/main.scala:87-91), so the samples-per-pixel
-range is split over ranks, each rank accumulates radiance SUMS for all pixels
-into its own buffer, and one reduce(sum) to rank 0 (RCCL over xGMI when the
-backend is "nccl") combines them.  Because the random stream of a path is keyed
-on the GLOBAL sample index, the set of paths is the same for every rank count.
+over samples of one pixel, jvm/src/main/scala/main.scala:79-91), so a frame can
+be cut two ways:
+
+"samples": the samples-per-pixel range is split over ranks, each rank
+  accumulates radiance SUMS for all pixels into its own buffer, and one
+  reduce(sum) to rank 0 (RCCL over xGMI when the backend is "nccl") combines
+  them: 24 bytes per pixel through the collective.
+"tiles": the frame's 8x8-pixel tiles are dealt out round-robin (rank g owns the
+  tiles g, g + G, ...), each rank renders every sample of its own tiles,
+  resolves them itself, and rank 0 gathers the packed pictures: 4 bytes per
+  pixel, 1/G of it from each rank, and nothing is added.
+
+Because the random stream of a path is keyed on (pixel, GLOBAL sample index)
+and the sums are integers, both give the one-rank frame bit for bit.
 """
 from __future__ import annotations
 
@@ -23,6 +32,14 @@ def shard_samples(samples: int, rank: int, world: int) -> Tuple[int, int]:
     count = base + (1 if rank < extra else 0)
     first = rank * base + min(rank, extra)
     return first, count
+
+
+def shard_tiles(rank: int, world: int) -> Tuple[int, int]:
+    """(tile_first, tile_stride) of `rank` out of `world` ranks: the tiles rank, rank + world, ...
+    of the frame's row-major tile numbering (ht_render_params.tile_first / tile_stride)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad shard request")
+    return (rank, world) if world > 1 else (0, 1)
 
 
 def render_sharded(accumulate: Callable[[int, int], "object"], samples: int, rank: int, world: int,
@@ -46,21 +63,49 @@ class FrameSlot:
     frame overlap the start of the next; the default does nothing)."""
 
     def __init__(self, accum, render_shard: Callable[[int, int, bool], None], resolve: Callable[[], None],
-                 stream: Callable[[], "object"] = None):
+                 stream: Callable[[], "object"] = None, tiles=None, tiles_all=None,
+                 resolve_tiles: Callable[[], None] = None, assemble: Callable[[], None] = None):
         import contextlib
 
         self.accum, self.render_shard, self.resolve = accum, render_shard, resolve
         self.stream = stream or contextlib.nullcontext
+        # tile sharding: `resolve_tiles()` writes this rank's own tiles into `tiles` (its packed tile
+        # buffer); `tiles_all` (rank 0) receives every rank's buffer, rank g's at g * len(tiles);
+        # `assemble()` (rank 0) makes the picture from it
+        self.tiles, self.tiles_all, self.resolve_tiles, self.assemble = tiles, tiles_all, resolve_tiles, assemble
 
 
-def make_frame_step(samples: int, rank: int, world: int, slots: List[FrameSlot], dist=None) -> Callable[[bool], None]:
+def make_frame_step(samples: int, rank: int, world: int, slots: List[FrameSlot], dist=None,
+                    mode: str = "samples") -> Callable[[bool], None]:
     """One frame as the benchmark and a multi-process host run it: zero this rank's sum
     buffer, add the rank's sample range into it, `dist.reduce(SUM)` to rank 0, and rank 0
     resolves the picture.  Successive frames take the slots in turn: with two slots on two
     streams the drain of frame k (its last long paths, its reduce and resolve) overlaps the
     render of frame k + 1.  `dist` is torch.distributed (None or world 1: no reduce)."""
+    if mode not in ("samples", "tiles"):
+        raise ValueError("mode must be 'samples' or 'tiles'")
     first, count = shard_samples(samples, rank, world)
     frame_no = [0]
+
+    def step_tiles(timed: bool) -> None:
+        # every sample of this rank's own tiles (render_shard knows which they are); the rank
+        # resolves them itself and rank 0 gathers the packed tile buffers: no sums travel
+        slot = slots[frame_no[0] % len(slots)]
+        frame_no[0] += 1
+        with slot.stream():
+            slot.accum.zero_()
+            if samples > 0:
+                slot.render_shard(0, samples, timed)
+            slot.resolve_tiles()
+            if world > 1:
+                n = slot.tiles.numel()
+                parts = [slot.tiles_all[g * n:(g + 1) * n] for g in range(world)] if rank == 0 else None
+                dist.gather(slot.tiles, gather_list=parts, dst=0)
+            if rank == 0:
+                slot.assemble()
+
+    if mode == "tiles":
+        return step_tiles
 
     def step(timed: bool) -> None:
         slot = slots[frame_no[0] % len(slots)]

@@ -54,6 +54,10 @@ def load() -> C.CDLL:
                                     A._pf32, A._pu32, C.POINTER(A.ht_stats)]
     L.ht_resolve.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, A._pf32, A._pu32, vp]
     L.ht_resolve_device.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, vp, vp, vp]
+    L.ht_shard_tile_pixels.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    L.ht_shard_tile_pixels.restype = C.c_int64
+    L.ht_resolve_tiles_device.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, vp, vp, vp]
+    L.ht_assemble_tiles_device.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]
     L.ht_first_hit.argtypes = [vp, C.POINTER(A.ht_camera), C.c_int32, C.c_int32, C.c_int32, A._pf32,
                                A._pi32, A._pf32, A._pf64, A._pf64]
     L.ht_cancel.argtypes = [vp]
@@ -91,12 +95,19 @@ def set_option(name: str, value: int):
 
 def make_params(width, height, samples, sample_offset=0, max_depth=50, jitter=1,
                 precision=A.HT_PRECISION_FP32, batch=0, seed=0, device=-1,
-                collect_counters=0) -> A.ht_render_params:
+                collect_counters=0, tile_first=0, tile_stride=0,
+                shard_mode=A.HT_SHARD_SAMPLES) -> A.ht_render_params:
     p = A.ht_render_params()
     p.width, p.height, p.samples, p.sample_offset = width, height, samples, sample_offset
     p.max_depth, p.jitter, p.precision, p.batch = max_depth, jitter, precision, batch
     p.seed, p.device, p.collect_counters = seed, device, collect_counters
+    p.tile_first, p.tile_stride, p.shard_mode = tile_first, tile_stride, shard_mode
     return p
+
+
+def shard_tile_pixels(width: int, height: int, n_shards: int) -> int:
+    """Pixels in one shard's tile buffer when a frame's 8x8 tiles are dealt out to `n_shards` shards."""
+    return int(load().ht_shard_tile_pixels(width, height, n_shards))
 
 
 class Scene:
@@ -177,6 +188,21 @@ class Scene:
         """ht_resolve_device: both outputs are DEVICE addresses (0 = skip)."""
         _check(load().ht_resolve_device(self._h, C.c_void_p(accum_ptr), width, height, total_samples,
                                         C.c_void_p(rgb_ptr), C.c_void_p(packed_ptr), C.c_void_p(stream)))
+
+    def resolve_tiles_device(self, accum_ptr: int, width: int, height: int, total_samples: int, tile_first: int,
+                             tile_stride: int, mean_tiles_ptr: int, packed_tiles_ptr: int, stream: int = 0):
+        """ht_resolve_tiles_device: the tiles (tile_first, tile_stride) of the frame into compact tile
+        buffers on the device (addresses as int, 0 = skip)."""
+        _check(load().ht_resolve_tiles_device(self._h, C.c_void_p(accum_ptr), width, height, total_samples, tile_first,
+                                              tile_stride, C.c_void_p(mean_tiles_ptr), C.c_void_p(packed_tiles_ptr),
+                                              C.c_void_p(stream)))
+
+    def assemble_tiles_device(self, width: int, height: int, n_shards: int, mean_tiles_all_ptr: int,
+                              packed_tiles_all_ptr: int, rgb_ptr: int, packed_ptr: int, stream: int = 0):
+        """ht_assemble_tiles_device: the frame from the gathered tile buffers of all shards."""
+        _check(load().ht_assemble_tiles_device(self._h, width, height, n_shards, C.c_void_p(mean_tiles_all_ptr),
+                                               C.c_void_p(packed_tiles_all_ptr), C.c_void_p(rgb_ptr),
+                                               C.c_void_p(packed_ptr), C.c_void_p(stream)))
 
     def first_hit(self, camera, width, height, precision=A.HT_PRECISION_FP32):
         t = np.zeros((height, width), dtype=np.float32)

@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from raytracing_amd.distributed import shard_samples
+from raytracing_amd.distributed import shard_samples, shard_tiles
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -129,3 +129,43 @@ def test_bench_frame_loop_two_ranks_gloo(tmp_path):
     assert r1["calls"] == [(6, 5, False)] + [(6, 5, True)] * 3
     # one elapsed time for the job: the slow rank's, on both ranks
     assert r0["elapsed"] == r1["elapsed"] >= 3 * 0.03
+
+
+def test_shard_tiles():
+    assert shard_tiles(0, 1) == (0, 1)
+    assert [shard_tiles(r, 4) for r in range(4)] == [(0, 4), (1, 4), (2, 4), (3, 4)]
+    with pytest.raises(ValueError):
+        shard_tiles(4, 4)
+
+
+def _run_bench(*flags, env_extra=None):
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, env=env,
+                       timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+@pytest.mark.parametrize("shard", ["tiles", "samples"])
+def test_bench_starts_its_own_ranks(shard):
+    """Plain `python bench.py --gpus 2` (no WORLD_SIZE in the environment) must run TWO ranks: the
+    script starts torch.distributed.run itself.  Driven here with the stand-in renderer over gloo
+    (no GPU), through the same launcher branch and the same frame loop; the one JSON line says how
+    many ranks the process group really had, and the frame equals its closed form."""
+    r, out = _run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--shard", shard, "--selftest-standin")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(out) == 1, r.stdout
+    line = out[0]
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["steps"] == 2
+    assert line["shard"] == shard and line["frame_equals_closed_form"] is True
+
+
+def test_bench_refuses_a_process_group_of_the_wrong_size():
+    """--gpus 4 inside a 2-rank job is an error, not a silent 2-rank measurement."""
+    r, out = _run_bench("--gpus", "4", "--selftest-standin", env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and not out
+    assert "WORLD_SIZE=2" in r.stderr
