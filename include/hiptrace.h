@@ -397,7 +397,16 @@ int ht_scene_get_info(const ht_scene* scene, ht_scene_info* out);
  *                       point may differ in its last bit).  The calls then synchronise with the stream.
  *   "wavefront_paths"   paths in flight of the wavefront variant (2^12..2^26, default 2^24)
  *   "wavefront_refill"  idle lanes of a trace wave that trigger a refill from the ray list (default 32) */
+/*   "timeline"          1: render launches record, per 10.24 us bin of the device's 100 MHz clock, how
+ *                       many work units their waves fetched, how many waves found the queue empty and
+ *                       how many ended (profiling; read with ht_debug_timeline) */
 int ht_set_option(const char* name, int value);
+
+/* Profiling aid (no counterpart in the reference): the counters of the option "timeline" for the
+ * launches of this scene since the last call, then cleared.  out receives 3 x 4096 words: units
+ * fetched, waves that found the queue empty, waves that ended; word k of each block counts the
+ * events in the bin (device clock ticks / 1024) mod 4096.  Waits for the device. */
+int ht_debug_timeline(ht_scene* scene, uint32_t* out, int32_t n_words);
 
 #ifdef __cplusplus
 }

@@ -163,4 +163,5 @@ EXPORTS = [
     "ht_last_error",
     "ht_scene_get_info",
     "ht_set_option",
+    "ht_debug_timeline",
 ]

@@ -63,6 +63,10 @@ struct ht_scene {
   float* d_host_mean = nullptr;
   uint32_t* d_host_packed = nullptr;
   size_t host_accum_pixels = 0, host_mean_pixels = 0, host_packed_pixels = 0;
+  // profiling: per-time-bin counters that the render kernels of this handle add to while the
+  // option "timeline" is on (ht_debug_timeline reads and clears them)
+  std::mutex timeline_mutex;
+  uint32_t* d_timeline = nullptr;
   // HIP events of finished calls, reused by later ones
   std::mutex event_mutex;
   std::vector<hipEvent_t> timing_events, plain_events;
@@ -128,6 +132,7 @@ std::atomic<int> g_force_hbm{0};     // scenes created while set keep their imag
 std::atomic<int> g_wavefront{0};      // 1: fp32 renders run the wavefront variant
 std::atomic<int> g_wavefront_cap{1 << 24};  // paths in flight of the wavefront variant
 std::atomic<int> g_wavefront_refill{32};    // idle lanes of a trace wave that trigger a refill
+std::atomic<int> g_timeline{0};            // 1: render launches record when their waves fetch units and end
 std::atomic<int> g_shape_generation{0};  // bumped by the options a launch shape depends on
 
 // Makes `device` current for the lifetime of the object, then restores.
@@ -350,6 +355,19 @@ int make_plan(ht_scene* s, const ht_camera* cam, const ht_render_params* p, int6
   a.inv_h1 = 1.0f / (float)(p->height - 1);
   a.tile_stride = std::max(1, p->tile_stride);
   a.tile_first = p->tile_first;
+  a.timeline = nullptr;
+  if (g_timeline.load() != 0) {
+    std::lock_guard<std::mutex> lock(s->timeline_mutex);
+    if (!s->d_timeline) {
+      hipError_t e = hipMalloc((void**)&s->d_timeline, 3u * TIMELINE_BINS * sizeof(uint32_t));
+      if (e == hipSuccess) e = hipMemset(s->d_timeline, 0, 3u * TIMELINE_BINS * sizeof(uint32_t));
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(HT_E_HIP, "allocation of the timeline failed: %s", hipGetErrorString(e));
+      }
+    }
+    a.timeline = s->d_timeline;
+  }
 
   int batch = p->batch > 0 ? p->batch : g_default_batch.load();
   // the work queue of one launch is indexed with 32 bits: tiles x sample chunks
@@ -618,6 +636,7 @@ int ht_set_option(const char* name, int value) {
   if (!strcmp(name, "node_den")) { g_node_den = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "wait_ratio_num")) { g_wait_num = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "wait_ratio_den")) { g_wait_den = std::max(1, value); return HT_OK; }
+  if (!strcmp(name, "timeline")) { g_timeline = value ? 1 : 0; return HT_OK; }
   if (!strcmp(name, "gpu_bvh")) { g_gpu_bvh_min = std::max(0, value); return HT_OK; }
   if (!strcmp(name, "force_hbm_scene")) { g_force_hbm = value ? 1 : 0; return HT_OK; }
   if (!strcmp(name, "wavefront")) { g_wavefront = value ? 1 : 0; return HT_OK; }
@@ -636,6 +655,7 @@ void ht_scene_destroy(ht_scene* s) {
     if (s->d_queue_heads) (void)hipFree(s->d_queue_heads);
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->d_wf) (void)hipFree(s->d_wf);
+    if (s->d_timeline) (void)hipFree(s->d_timeline);
     if (s->d_host_accum) (void)hipFree(s->d_host_accum);
     if (s->d_host_mean) (void)hipFree(s->d_host_mean);
     if (s->d_host_packed) (void)hipFree(s->d_host_packed);
@@ -754,6 +774,19 @@ int ht_scene_get_info(const ht_scene* s, ht_scene_info* out) {
   out->hbm_store_fp32 = (int32_t)s->hs.layout32.wide;
   out->hbm_store_fp64 = (int32_t)s->hs.layout64.wide;
   out->device = s->device;
+  return HT_OK;
+}
+
+int ht_debug_timeline(ht_scene* s, uint32_t* out, int32_t n_words) {
+  if (!s || !out) return fail(HT_E_INVALID, "NULL argument");
+  if (n_words != (int32_t)(3u * TIMELINE_BINS)) return fail(HT_E_INVALID, "the timeline has %u words", 3u * TIMELINE_BINS);
+  DeviceGuard g(s->device);
+  if (!g.ok) return fail(HT_E_NO_DEVICE, "cannot select device %d", s->device);
+  std::lock_guard<std::mutex> lock(s->timeline_mutex);
+  if (!s->d_timeline) return fail(HT_E_INVALID, "no launch of this scene ran with the option \"timeline\" on");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, s->d_timeline, 3u * TIMELINE_BINS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(s->d_timeline, 0, 3u * TIMELINE_BINS * sizeof(uint32_t)));
   return HT_OK;
 }
 

@@ -177,6 +177,8 @@ hipError_t lbvh_build(uint32_t n, const float* boxes, const float cent_lo[3], co
   LBVH_TRY(mem.get(&d_nodes, n - 1));
   LBVH_TRY(hipMemcpy(d_boxes, boxes, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice));
   LBVH_TRY(hipMemset(d_arrived, 0, (size_t)(n - 1) * sizeof(uint32_t)));
+  // a node the kernels never wrote must not look like one: all ones fail the host's index checks
+  LBVH_TRY(hipMemset(d_nodes, 0xFF, (size_t)(n - 1) * sizeof(LbvhNode)));
   LBVH_TRY(hipMemset(d_node_parent, 0, (size_t)(n - 1) * sizeof(uint32_t)));
   LBVH_TRY(hipMemset(d_leaf_parent, 0, (size_t)n * sizeof(uint32_t)));
 

@@ -541,9 +541,12 @@ bool textures_acyclic(const HostScene& hs) {
 
 // A hierarchy that came from outside -> the host's node array, depth first, with leaves of
 // two where both children of a node below the root are single triangles or single ordinary
-// spheres.  Everything about the input is checked (it was computed on another device): every
-// inner node and every primitive reached exactly once, indices in range, depth within
-// `max_levels`.  Returns false if anything is off; `nodes` and the pair lists are then garbage.
+// spheres.  Only the TOPOLOGY of the input is used, and all of it is checked (it was computed
+// on another device): every inner node and every primitive reached exactly once, indices in
+// range, depth within `max_levels`.  The child boxes are not taken from the input: every node's
+// are worked out here, bottom-up, as the union of the boxes of the primitives below it, so a
+// wrong or stale box from the device can never cull geometry.  Returns false if anything is
+// off; `nodes` and the pair lists are then garbage.
 struct ExternalConverter {
   const std::vector<ExternalNode>& in;
   const std::vector<Item>& items;
@@ -553,51 +556,59 @@ struct ExternalConverter {
   int max_levels, max_level = 0;
   bool ok = true;
 
-  uint32_t leaf(uint32_t r) {
+  uint32_t leaf(uint32_t r, Box& box) {
     const uint32_t i = r & ~EXTERNAL_LEAF;
     if (i >= items.size() || item_seen[i]) { ok = false; return WREF_EMPTY; }
     item_seen[i] = 1;
+    box = items[i].box;
     return items[i].ref;
   }
-  uint32_t convert(uint32_t g, int level) {
+  // the reference that stands for subtree g, and the box of everything below it
+  uint32_t convert(uint32_t g, int level, Box& box) {
+    box.reset();
     if (!ok) return WREF_EMPTY;
     if (g >= in.size() || node_seen[g] || level >= max_levels) { ok = false; return WREF_EMPTY; }
     node_seen[g] = 1;
     const ExternalNode& e = in[g];
+    Box cb[2];
+    cb[0].reset();
+    cb[1].reset();
     if (level > 0 && (e.child[0] & EXTERNAL_LEAF) && (e.child[1] & EXTERNAL_LEAF)) {
-      const uint32_t a = leaf(e.child[0]), b = leaf(e.child[1]);
+      const uint32_t a = leaf(e.child[0], cb[0]), b = leaf(e.child[1], cb[1]);
       if (!ok) return WREF_EMPTY;
+      box = cb[0];
+      box.grow(cb[1]);
       const uint32_t ka = (a >> WREF_KIND_SHIFT) & 7u, kb = (b >> WREF_KIND_SHIFT) & 7u;
       if (ka == kb && (ka == KIND_TRIANGLE || ka == KIND_SPHERE)) {
         auto& list = ka == KIND_TRIANGLE ? tri_pairs : sph_pairs;
         list.emplace_back(a & WREF_INDEX_MASK, b & WREF_INDEX_MASK);
         return WREF_LEAF | ((ka == KIND_TRIANGLE ? KIND_TRI_PAIR : KIND_SPH_PAIR) << WREF_KIND_SHIFT) | (uint32_t)(list.size() - 1);
       }
-      return emit(e, a, b, level);
+      const uint32_t idx = (uint32_t)nodes.size();
+      nodes.emplace_back();
+      max_level = std::max(max_level, level + 1);
+      fill(idx, cb, a, b);
+      return idx;
     }
     const uint32_t idx = (uint32_t)nodes.size();
     nodes.emplace_back();
     max_level = std::max(max_level, level + 1);
     uint32_t c[2];
     for (int k = 0; k < 2; ++k)
-      c[k] = (e.child[k] & EXTERNAL_LEAF) ? leaf(e.child[k]) : convert(e.child[k], level + 1);
-    fill(idx, e, c[0], c[1]);
+      c[k] = (e.child[k] & EXTERNAL_LEAF) ? leaf(e.child[k], cb[k]) : convert(e.child[k], level + 1, cb[k]);
+    if (!ok) return WREF_EMPTY;
+    fill(idx, cb, c[0], c[1]);
+    box = cb[0];
+    box.grow(cb[1]);
     return idx;
   }
-  uint32_t emit(const ExternalNode& e, uint32_t a, uint32_t b, int level) {
-    const uint32_t idx = (uint32_t)nodes.size();
-    nodes.emplace_back();
-    max_level = std::max(max_level, level + 1);
-    fill(idx, e, a, b);
-    return idx;
-  }
-  void fill(uint32_t idx, const ExternalNode& e, uint32_t c0, uint32_t c1) {
+  void fill(uint32_t idx, const Box cb[2], uint32_t c0, uint32_t c1) {
     BvhNode& nd = nodes[idx];
     for (int k = 0; k < 2; ++k)
       for (int a = 0; a < 3; ++a) {
-        nd.lo[k][a] = e.lo[k][a];
-        nd.hi[k][a] = e.hi[k][a];
-        if (!(e.lo[k][a] <= e.hi[k][a])) ok = false;  // NaN, or a box turned inside out
+        nd.lo[k][a] = cb[k].lo[a];
+        nd.hi[k][a] = cb[k].hi[a];
+        if (!(cb[k].lo[a] <= cb[k].hi[a])) ok = false;  // NaN, or an empty subtree
       }
     nd.child[0] = c0;
     nd.child[1] = c1;
@@ -843,7 +854,8 @@ int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err, co
         ExternalConverter cv{ext, items, hs.nodes, tri_pairs, sph_pairs, std::vector<uint8_t>(ext.size(), 0),
                              std::vector<uint8_t>((size_t)nb, 0), max_levels};
         hs.nodes.reserve(ext.size());
-        const uint32_t r = cv.convert(0u, 0);
+        Box whole;
+        const uint32_t r = cv.convert(0u, 0, whole);
         bool all = cv.ok && r == 0u;
         for (size_t k = 0; all && k < cv.node_seen.size(); ++k) all = cv.node_seen[k] != 0;
         for (size_t k = 0; all && k < cv.item_seen.size(); ++k) all = cv.item_seen[k] != 0;

@@ -42,7 +42,11 @@ struct RenderArgs {
   float inv_w1, inv_h1;    // 1/(W-1), 1/(H-1) correctly rounded (jittered fp32 sample positions)
   int32_t tile_first;      // this launch renders the 8x8 tiles tile_first, tile_first + tile_stride, ... of the
   int32_t tile_stride;     //   frame (row-major tile numbers); 0 / 1: every tile
+  uint32_t* timeline;      // nullptr, or 3 x TIMELINE_BINS counters of a profiling run: work units fetched,
+                           //   waves that found the queue empty, waves that ended, per time bin
 };
+// a timeline bin is 1024 ticks of the 100 MHz s_memrealtime clock (10.24 us); bin = (ticks >> 10) mod TIMELINE_BINS
+constexpr uint32_t TIMELINE_BINS = 4096;
 
 // ---- wavefront variant: the same paths as render_kernel, one kernel per stage ----------
 // Path state lives in global memory between the stages, structure-of-arrays with `cap`

@@ -1215,6 +1215,9 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
         // every lane is here (the loop's control is wave-uniform); read as a scalar, so that
         // the unit's state lives in scalar registers and the loop branches on scalars
         unit = __builtin_amdgcn_readfirstlane(unit);
+        if (ca->timeline != nullptr && lane == 0)  // profiling run: when units are fetched
+          atomicAdd(ca->timeline + (unit >= n_units ? TIMELINE_BINS : 0u) +
+                        (((uint32_t)(__builtin_amdgcn_s_memrealtime() >> 10)) & (TIMELINE_BINS - 1u)), 1u);
         if (unit >= n_units) {
           queue_empty = true;
           epoch++;  // whatever is still in flight deposits to the frame directly
@@ -1335,6 +1338,12 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
   // the last unit's sums (epoch was bumped when the queue ran dry, so every later
   // deposit went to the frame; what is left in LDS belongs to the last real unit)
   flush_tile();
+  {
+    const auto* ca = kernarg_args();
+    if (ca->timeline != nullptr && lane == 0)  // profiling run: when waves end
+      atomicAdd(ca->timeline + 2u * TIMELINE_BINS +
+                    (((uint32_t)(__builtin_amdgcn_s_memrealtime() >> 10)) & (TIMELINE_BINS - 1u)), 1u);
+  }
 
   if (CNT && A.counters) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {

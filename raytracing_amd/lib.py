@@ -63,6 +63,7 @@ def load() -> C.CDLL:
     L.ht_cancel.argtypes = [vp]
     L.ht_scene_get_info.argtypes = [vp, C.POINTER(A.ht_scene_info)]
     L.ht_set_option.argtypes = [C.c_char_p, C.c_int]
+    L.ht_debug_timeline.argtypes = [vp, A._pu32, C.c_int32]
     L.ht_frame_create.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.ht_frame_destroy.argtypes = [vp]
     L.ht_frame_destroy.restype = None
@@ -143,6 +144,13 @@ class Scene:
         i = A.ht_scene_info()
         _check(load().ht_scene_get_info(self._h, C.byref(i)))
         return {k: getattr(i, k) for k, _ in A.ht_scene_info._fields_}
+
+    def debug_timeline(self) -> np.ndarray:
+        """ht_debug_timeline: [3, 4096] counts per 10.24 us bin (units fetched, waves that found the
+        queue empty, waves that ended) of the launches made while the option "timeline" was on."""
+        out = np.zeros((3, 4096), dtype=np.uint32)
+        _check(load().ht_debug_timeline(self._h, out.ctypes.data_as(A._pu32), out.size))
+        return out
 
     def cancel(self):
         _check(load().ht_cancel(self._h))

@@ -33,10 +33,37 @@ def camera_rays(cam, W, H):
     return origin, direction  # direction [H, W, 3], not normalised
 
 
-def first_hit(cam, prim_type, prim_data, W, H, t_min=0.001):
+def camera_rays_fp32_arithmetic(cam, W, H):
+    """The same rays as a device that holds the camera basis in fp32 and does the arithmetic in
+    fp32 would make them: corner = float32(lower_left_corner - origin) (subtracted in fp64 first),
+    s = float32(i + 0.5) / float32(W - 1), direction = fma(t, vertical, fma(s, horizontal, corner)).
+    Returned as float64 arrays holding fp32 values.  (A fused multiply-add of floats is the
+    float64 product, exact, plus the addend, rounded once to float64 and once more to float32.)"""
+    origin, target, vup = (np.asarray(x, dtype=np.float64) for x in (cam.origin, cam.target, cam.vup))
+    viewport_height = 2.0 * np.tan(np.radians(cam.vfov) / 2)
+    viewport_width = cam.aspect_ratio * viewport_height
+    w = unit(origin - target)
+    u = unit(np.cross(vup, w))
+    v = np.cross(w, u)
+    focus = np.sqrt(((target - origin) ** 2).sum()) if cam.focus_distance < 0 else cam.focus_distance
+    horizontal = focus * viewport_width * u
+    vertical = focus * viewport_height * v
+    lower_left_corner = origin - horizontal / 2 - vertical / 2 - focus * w
+    f32 = lambda x: np.asarray(x, dtype=np.float32).astype(np.float64)
+    corner, hor, ver, org = f32(lower_left_corner - origin), f32(horizontal), f32(vertical), f32(origin)
+    s = (np.arange(W, dtype=np.float32) + np.float32(0.5)) / np.float32(W - 1)
+    t = (np.arange(H, dtype=np.float32) + np.float32(0.5)) / np.float32(H - 1)
+    s, t = s.astype(np.float64), t.astype(np.float64)
+    inner = f32(s[None, :, None] * hor[None, None, :] + corner[None, None, :])
+    direction = f32(t[:, None, None] * ver[None, None, :] + inner)
+    return org, np.broadcast_to(direction, (H, W, 3)).copy()
+
+
+def first_hit(cam, prim_type, prim_data, W, H, t_min=0.001, rays=None):
     """Returns t [H, W] (inf on a miss), prim id [H, W] (-1), Hit.normal [H, W, 3] and a
-    mask of pixels whose two closest hits are too close to call."""
-    o, d = camera_rays(cam, W, H)
+    mask of pixels whose two closest hits are too close to call.  rays: (origin [3],
+    direction [H, W, 3]) to trace instead of the camera's own."""
+    o, d = camera_rays(cam, W, H) if rays is None else rays
     best_t = np.full((H, W), np.inf)
     second_t = np.full((H, W), np.inf)
     best_id = np.full((H, W), -1, dtype=np.int32)

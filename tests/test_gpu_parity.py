@@ -10,11 +10,15 @@ Tolerances
     perturbation (a ray stored in fp32 is only defined to ~1e-7 relative, and grazing
     hits amplify that).  The share of hit pixels inside the PLAIN 1e-5 is printed and
     asserted per scene: >= 99.9 % for t on every scene, >= 99.9 % for normals on every
-    scene but random.json (>= 99.4 %).  random.json is the one scene where fp32 rays cannot
-    do better: its 0.2-radius spheres stand 10-25 units from the camera, so the 2^-24
-    rounding of a ray direction moves the hit point by ~1.5e-6 and the normal by ~1e-5;
-    the oracle itself, fed camera rays rounded to fp32 and tracing them in fp64, leaves
-    0.11 % of that scene's normals outside 1e-5 (tests/test_oracle_kat.py pins that floor).
+    scene but random.json (>= 99.55 %, measured 99.61 %).  random.json is the one scene where
+    fp32 rays cannot do better: its 0.2-radius spheres stand 10-25 units from the camera, so the
+    2^-24 rounding of a ray direction moves the hit point by ~1.5e-6 and the normal by ~1e-5.
+    Two floors are pinned on the CPU: the oracle fed exact camera rays rounded ONCE to fp32 and
+    tracing them in fp64 leaves 0.11 % of that scene's normals outside 1e-5
+    (tests/test_oracle_kat.py); rays MADE in fp32 as the device makes them (fp32 basis, two
+    fused multiply-adds per component) and then traced exactly leave 0.35 %, p99.9 1.74e-5
+    (tests/test_numpy_mirror.py).  The device leaves 0.39 %, p99.9 1.75e-5: its intersection
+    and hit-point arithmetic add next to nothing to the error of its ray.
   * matched-stream renders (same Philox-keyed paths on both sides): >= 99 % of the
     pixels within 2e-3 absolute and PSNR >= 45 dB on the 8-bit toRGB codes; the rest
     are paths where fp32 rounding flipped a discrete decision.
@@ -105,7 +109,7 @@ def test_first_hit_fp32_matches_oracle(dev, oracle_mod, flat_scene, name):
               f"normal {n_in:.5f} (max {nerr.max():.2e}, p99.9 {np.percentile(nerr, 99.9):.2e}); "
               f"ids differ on {int(mism.sum())} unstable pixels")
         assert t_in >= 0.999, f"{name}: {1 - t_in:.2e} of the hit pixels have t outside 1e-5"
-        floor = 0.994 if name == "random" else 0.999
+        floor = 0.9955 if name == "random" else 0.999
         assert n_in >= floor, f"{name}: {1 - n_in:.2e} of the hit pixels have the normal outside 1e-5"
     # misses are +inf / -1 / zero normal
     miss = ~hit & ~mism

@@ -22,3 +22,27 @@ def test_oracle_first_hit_equals_numpy_restatement(oracle_mod, flat_scene, name)
     assert np.all(np.isinf(o["t"][ok & (pid < 0)]))
     np.testing.assert_allclose(o["t"][hit], t[hit], rtol=1e-12)
     np.testing.assert_allclose(o["normal"][hit], n[hit], rtol=1e-9, atol=1e-12)
+
+
+def test_fp32_arithmetic_ray_floor_on_random_json(flat_scene):
+    """How good can the first-hit normals of random.json be when the camera ray itself is MADE in
+    fp32 (basis rounded to fp32, two fused multiply-adds per component), as the device makes it,
+    and everything after it is exact?  Traced in fp64 by the numpy restatement against the exact
+    rays.  A ray rounded once from the exact direction leaves ~0.11 % of the normals outside 1e-5
+    (tests/test_oracle_kat.py); a ray computed in fp32 carries about twice that error, and the
+    share outside grows to 0.3-0.5 %: the device's own figure (0.39 %, tests/test_gpu_parity.py)
+    is this floor, not an error of its intersection or hit-point arithmetic."""
+    from numpy_first_hit import camera_rays_fp32_arithmetic
+
+    cam, _, flat = flat_scene("random")
+    W, H = 320, 180
+    t, pid, n, tie = first_hit(cam, flat.prim_type, flat.prim_data, W, H)
+    t32, pid32, n32, tie32 = first_hit(cam, flat.prim_type, flat.prim_data, W, H,
+                                       rays=camera_rays_fp32_arithmetic(cam, W, H))
+    same = (pid >= 0) & (pid == pid32) & ~tie & ~tie32
+    assert same.mean() > 0.5 and (pid != pid32).mean() < 1e-3
+    nerr = np.linalg.norm(n32[same] - n[same], axis=-1) / np.linalg.norm(n[same], axis=-1)
+    outside = float((nerr > 1e-5).mean())
+    print(f"random.json, rays made in fp32 and traced in fp64: {outside:.5f} of the normals outside 1e-5, "
+          f"p99.9 {np.percentile(nerr, 99.9):.2e}, max {nerr.max():.2e}")
+    assert 2.0e-3 < outside < 6.0e-3
