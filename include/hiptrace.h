@@ -365,6 +365,9 @@ typedef struct ht_scene_info {
   int32_t hbm_store_fp32, hbm_store_fp64; /* 0: the image is traversed in LDS (on-chip
                                              store); 1: it is too large for that and is
                                              traversed where it lies in HBM               */
+  double sah_before, sah_after;           /* surface-area cost of the hierarchy (sum of the half-areas
+                                             of its inner nodes' boxes) as built and after the
+                                             optimiser (option "bvh_optimise"); 0: not run  */
 } ht_scene_info;
 int ht_scene_get_info(const ht_scene* scene, ht_scene_info* out);
 
@@ -397,7 +400,9 @@ int ht_scene_get_info(const ht_scene* scene, ht_scene_info* out);
  *                       point may differ in its last bit).  The calls then synchronise with the stream.
  *   "wavefront_paths"   paths in flight of the wavefront variant (2^12..2^26, default 2^24)
  *   "wavefront_refill"  idle lanes of a trace wave that trigger a refill from the ray list (default 32) */
-/*   "timeline"          1: render launches record, per 10.24 us bin of the device's 100 MHz clock, how
+/*   "bvh_optimise"      passes of the insertion-based optimiser over the hierarchy of scenes created from
+ *                       now on (default 4; 0: the hierarchy stays as the top-down builder made it)
+ *   "timeline"          1: render launches record, per 10.24 us bin of the device's 100 MHz clock, how
  *                       many work units their waves fetched, how many waves found the queue empty and
  *                       how many ended (profiling; read with ht_debug_timeline) */
 int ht_set_option(const char* name, int value);

@@ -135,6 +135,8 @@ class ht_scene_info(C.Structure):
         ("device", C.c_int32),
         ("hbm_store_fp32", C.c_int32),
         ("hbm_store_fp64", C.c_int32),
+        ("sah_before", C.c_double),
+        ("sah_after", C.c_double),
     ]
 
 

@@ -227,6 +227,166 @@ struct Builder {
   }
 };
 
+// ---- hierarchy optimiser -------------------------------------------------------
+// Improves a finished hierarchy by removing subtrees and putting them back where they cost
+// least (Bittner, Hapala, Havran: "Fast insertion-based optimization of bounding volume
+// hierarchies", 2013).  The cost is the surface-area heuristic's: the sum of the areas of all
+// inner nodes' boxes, proportional to the expected number of node visits of a random ray.  A
+// top-down builder fixes every split before it has seen what is below it; the low-polygon meshes
+// of the reference (long thin triangles, a few hundred of them) leave it 10-20 % to find.
+// Leaves (single primitives and the leaves of two) are moved whole.  The depth of the result
+// never exceeds `max_depth`: every level is two bytes of traversal stack per lane.
+struct Optimiser {
+  struct TNode {
+    Box box;
+    int parent = -1, c[2] = {-1, -1};  // c[0] < 0: a leaf
+    uint32_t ref = 0;                  // leaf reference
+    int h = 0;                         // levels of inner nodes at and below this node
+  };
+  std::vector<TNode> t;
+  int root = 0, max_depth = 0;
+
+  int add(const std::vector<BvhNode>& nodes, uint32_t ref, const Box& box, int parent) {
+    const int idx = (int)t.size();
+    t.emplace_back();
+    t[idx].box = box;
+    t[idx].parent = parent;
+    if (ref & WREF_LEAF) {
+      t[idx].ref = ref;
+      return idx;
+    }
+    const BvhNode& nd = nodes[ref];
+    int h = 0;
+    for (int k = 0; k < 2; ++k) {
+      Box cb;
+      for (int a = 0; a < 3; ++a) { cb.lo[a] = nd.lo[k][a]; cb.hi[a] = nd.hi[k][a]; }
+      const int ci = add(nodes, nd.child[k], cb, idx);
+      t[idx].c[k] = ci;
+      h = std::max(h, t[ci].h);
+    }
+    t[idx].h = h + 1;
+    return idx;
+  }
+  void refit_from(int i) {
+    for (; i >= 0; i = t[i].parent) {
+      TNode& n = t[i];
+      n.box = t[n.c[0]].box;
+      n.box.grow(t[n.c[1]].box);
+      n.h = 1 + std::max(t[n.c[0]].h, t[n.c[1]].h);
+    }
+  }
+  double cost() const {
+    double c = 0;
+    for (const TNode& n : t)
+      if (n.c[0] >= 0) c += n.box.half_area();
+    return c;
+  }
+  static double joined_area(const Box& a, const Box& b) {
+    Box u = a;
+    u.grow(b);
+    return u.half_area();
+  }
+  // takes n out (its parent p goes with it, the sibling moves up) and puts it back at the
+  // cheapest place; p is reused as the new parent
+  void reinsert(int n) {
+    const int p = t[n].parent;
+    if (p < 0 || p == root) return;
+    const int g = t[p].parent, s = t[p].c[0] == n ? t[p].c[1] : t[p].c[0];
+    t[g].c[t[g].c[0] == p ? 0 : 1] = s;
+    t[s].parent = g;
+    refit_from(g);
+    // best-first search over the places x: the new parent of (x, n) takes x's place
+    struct Cand { double induced; int node, level; };
+    auto later = [](const Cand& a, const Cand& b) { return a.induced > b.induced; };
+    std::vector<Cand> heap;
+    heap.push_back(Cand{0.0, root, 0});
+    const double area_n = t[n].box.half_area();
+    double best_cost = std::numeric_limits<double>::infinity();
+    int best = -1;
+    while (!heap.empty()) {
+      std::pop_heap(heap.begin(), heap.end(), later);
+      const Cand c = heap.back();
+      heap.pop_back();
+      if (c.induced + area_n >= best_cost) break;  // nothing that is left can do better
+      const TNode& x = t[c.node];
+      const double direct = joined_area(x.box, t[n].box), total = c.induced + direct;
+      if (total < best_cost && c.level + 1 + std::max(x.h, t[n].h) <= max_depth) {
+        best_cost = total;
+        best = c.node;
+      }
+      if (x.c[0] >= 0) {
+        const double below = total - x.box.half_area();  // what n adds to x's own box
+        if (below + area_n < best_cost && c.level + 2 + t[n].h <= max_depth)
+          for (int k = 0; k < 2; ++k) {
+            heap.push_back(Cand{below, x.c[k], c.level + 1});
+            std::push_heap(heap.begin(), heap.end(), later);
+          }
+      }
+    }
+    if (best < 0) best = s;  // cannot happen (the old place satisfies the depth bound); stay safe
+    const int gx = t[best].parent;
+    t[p].c[0] = best;
+    t[p].c[1] = n;
+    t[p].parent = gx;
+    t[best].parent = p;
+    t[n].parent = p;
+    if (gx >= 0) t[gx].c[t[gx].c[0] == best ? 0 : 1] = p;
+    else root = p;
+    refit_from(p);
+  }
+  uint32_t write(int i, std::vector<BvhNode>& out) const {
+    if (t[i].c[0] < 0) return t[i].ref;
+    const uint32_t idx = (uint32_t)out.size();
+    out.emplace_back();
+    for (int k = 0; k < 2; ++k) {
+      const uint32_t r = write(t[i].c[k], out);
+      BvhNode& nd = out[idx];
+      nd.child[k] = r;
+      const Box& b = t[t[i].c[k]].box;
+      for (int a = 0; a < 3; ++a) { nd.lo[k][a] = b.lo[a]; nd.hi[k][a] = b.hi[a]; }
+    }
+    return idx;
+  }
+};
+
+// Runs the optimiser over `nodes` (node 0 = root) in place; `depth` is the hierarchy's depth and
+// the bound the result keeps.  Returns the cost before and after in `before` / `after`.
+void optimise_hierarchy(std::vector<BvhNode>& nodes, int& depth, int passes, double& before, double& after) {
+  before = after = 0;
+  if (nodes.size() < 3 || passes <= 0) return;
+  Optimiser o;
+  o.t.reserve(nodes.size() * 2 + 1);
+  o.max_depth = depth;
+  Box rb;
+  rb.reset();
+  for (int k = 0; k < 2; ++k)
+    for (int a = 0; a < 3; ++a) {
+      rb.lo[a] = std::min(rb.lo[a], nodes[0].lo[k][a]);
+      rb.hi[a] = std::max(rb.hi[a], nodes[0].hi[k][a]);
+    }
+  o.root = o.add(nodes, 0u, rb, -1);
+  before = after = o.cost();
+  std::vector<int> order;
+  for (int pass = 0; pass < passes; ++pass) {
+    // large boxes first: they are the ones that sit in the wrong place most expensively
+    order.clear();
+    for (int i = 0; i < (int)o.t.size(); ++i)
+      if (i != o.root) order.push_back(i);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int x, int y) { return o.t[x].box.half_area() > o.t[y].box.half_area(); });
+    for (int n : order) o.reinsert(n);
+    const double now = o.cost();
+    const bool done = now > after * 0.998;
+    after = now;
+    if (done) break;
+  }
+  std::vector<BvhNode> out;
+  out.reserve(nodes.size());
+  o.write(o.root, out);
+  nodes.swap(out);
+  depth = o.t[o.root].h;
+}
+
 // ---- blob writer -------------------------------------------------------------
 template <typename R> R round_down(double d);
 template <typename R> R round_up(double d);
@@ -955,6 +1115,8 @@ int build_host_scene(const ht_scene_desc* d, HostScene& hs, std::string& err, co
     hs.nodes.resize(n_nodes);
     }
   }
+  if (opt.optimise_passes > 0 && hs.nodes.size() <= (size_t)opt.optimise_max_nodes)
+    optimise_hierarchy(hs.nodes, hs.depth, opt.optimise_passes, hs.sah_before, hs.sah_after);
   {
     // the two primitives of a pair must be neighbours in the array of their kind: flagged
     // primitives first (the big spheres, never part of a pair), then the pairs in the order

@@ -41,6 +41,7 @@ struct HostScene {
   double root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
   int depth = 0;
   bool external_bvh_used = false;   // the hierarchy came from BuildOptions::external_bvh
+  double sah_before = 0, sah_after = 0;  // sum of the inner nodes' box half-areas before / after the optimiser
 
   SceneLayout layout32{}, layout64{};
   std::vector<uint8_t> blob32, blob64;
@@ -67,6 +68,10 @@ struct BuildOptions {
   ExternalBvhBuilder external_bvh = nullptr;
   void* external_ctx = nullptr;
   int external_min_prims = 0;
+  // insertion-based optimisation of the finished hierarchy: passes over all nodes (0: off), for
+  // hierarchies of at most optimise_max_nodes inner nodes
+  int optimise_passes = 4;
+  int optimise_max_nodes = 1 << 13;
 };
 
 // Validates `desc` and fills `out`; returns HT_OK or an error code with `err` set.

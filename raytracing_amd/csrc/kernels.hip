@@ -374,19 +374,27 @@ __device__ __forceinline__ bool sphere_solve(const Scene& sc, const Ray<R>& ray,
   o.big = kind == KIND_BIG_SPHERE;
   V3<R> oc = ray.o - o.cen;
   R hb = dot(oc, ray.d);
-  o.l = oc - (hb * ray.inv_a) * ray.d;
   const R r2 = o.rad * o.rad;
-  R c;
-  if (o.big) {
-    R K = *(const R*)(sc.base + sc.L.sph_k + idx * (uint32_t)sizeof(R));
-    c = ray.oo - (R)2 * dot(ray.o, o.cen) + K;
-  } else {
-    c = dot(oc, oc) - r2;
-  }
+  R c, disc;
   // two forms of the discriminant: from the closest-approach offset (accurate when
   // the origin is far from the sphere compared with its radius) or b^2 - a c
   // (accurate when the origin is on or near the surface)
-  const R disc = (c > (R)3 * r2) ? ray.a * (r2 - dot(o.l, o.l)) : hb * hb - ray.a * c;
+  if (o.big) {
+    // a sphere that dwarfs the scene: the rays start on or near it, the second form; the first
+    // only behind a branch that the lanes of a wave practically never take
+    R K = *(const R*)(sc.base + sc.L.sph_k + idx * (uint32_t)sizeof(R));
+    c = ray.oo - (R)2 * dot(ray.o, o.cen) + K;
+    disc = hb * hb - ray.a * c;
+    o.l = oc;
+    if (c > (R)3 * r2) {
+      o.l = oc - (hb * ray.inv_a) * ray.d;
+      disc = ray.a * (r2 - dot(o.l, o.l));
+    }
+  } else {
+    c = dot(oc, oc) - r2;
+    o.l = oc - (hb * ray.inv_a) * ray.d;
+    disc = (c > (R)3 * r2) ? ray.a * (r2 - dot(o.l, o.l)) : hb * hb - ray.a * c;
+  }
   if (!(disc > (R)0)) return false;
   R sq = M<R>::sqrt(disc);
   R q = -(hb + M<R>::copysign(sq, hb));
@@ -833,14 +841,30 @@ __device__ __forceinline__ V3<R> texture_eval(const Scene& sc, const uint32_t* _
   }
 }
 
-// Vec3.random_unit_vector (Vec3.scala:29-34) from two uniforms
+// The transcendental part of an event's sample: sine and cosine of one uniform (as an angle in
+// revolutions) and the square root of a second number.  A camera event needs them for the
+// point of the lens (Vec3.random_in_unit_disk, Vec3.scala:23-27: radius sqrt(u2), angle u3), a
+// scatter event for the direction (Vec3.random_unit_vector, Vec3.scala:29-34: angle u0,
+// radius sqrt(1 - z^2) with z = 2 u1 - 1).  The lanes of a wave are at both kinds of event in
+// the same round; worked out here once for all of them, the three slow instructions issue
+// once per round and not once per kind.
 template <typename R>
-__device__ __forceinline__ V3<R> unit_vector_from(R u0, R u1) {
-  R z = (R)2 * u1 - (R)1;
-  R r = M<R>::sqrt((R)1 - z * z);
-  R s, c;
-  M<R>::sincos2pi(u0, s, c);
-  return mk<R>(r * c, r * s, z);
+struct EventTrig {
+  R s, c, rr;
+};
+template <typename R>
+__device__ __forceinline__ EventTrig<R> event_trig(R angle, R radius_squared) {
+  EventTrig<R> t;
+  M<R>::sincos2pi(angle, t.s, t.c);
+  t.rr = M<R>::sqrt(radius_squared);
+  return t;
+}
+// what event_trig takes for a scatter event with uniforms u0, u1: angle u0, radius^2 = 1 - z^2
+template <typename R>
+__device__ __forceinline__ R scatter_z(R u1) { return (R)2 * u1 - (R)1; }
+template <typename R>
+__device__ __forceinline__ V3<R> unit_vector_from(const EventTrig<R>& t, R z) {
+  return mk<R>(t.rr * t.c, t.rr * t.s, z);
 }
 
 // Radiance sums are kept in signed 32.32 fixed point: integer adds commute, so a
@@ -944,16 +968,17 @@ __device__ __forceinline__ bool shade_surface(const Scene& sc, const uint32_t* _
 // Returns false when a Glossy bounce is absorbed (Material.scala:18-19).
 template <typename R>
 __device__ __forceinline__ bool scatter_direction(const Surface<R>& sf, const Ray<R>& ray,
-                                                  const uint32_t rnd[4], V3<R>& dir, bool diffuse_only) {
+                                                  const uint32_t rnd[4], const EventTrig<R>& trig, R z, V3<R>& dir,
+                                                  bool diffuse_only) {
   const V3<R> n = sf.n;
   if (diffuse_only || sf.mkind == 0u) {  // Diffuse
-    dir = n + unit_vector_from<R>(u01<R>(rnd[0]), u01<R>(rnd[1]));
+    dir = n + unit_vector_from<R>(trig, z);
     return true;
   }
   const V3<R> ud = M<R>::rsqrt(ray.a) * ray.d;  // ray.direction.unit_vector
   if (sf.mkind == 1u) {  // Glossy
     V3<R> refl = ud - ((R)2 * dot(ud, n)) * n;
-    V3<R> ball = M<R>::cbrt(u01<R>(rnd[2])) * unit_vector_from<R>(u01<R>(rnd[0]), u01<R>(rnd[1]));
+    V3<R> ball = M<R>::cbrt(u01<R>(rnd[2])) * unit_vector_from<R>(trig, z);
     dir = refl + sf.param * ball;
     return dot(dir, n) > (R)0;
   }
@@ -983,9 +1008,10 @@ __device__ __forceinline__ bool scatter_direction(const Surface<R>& sf, const Ra
 
 // Camera.get_ray (Camera.scala:19-23) for one sample of pixel (i, j)
 // (main.scala:88-89); rnd = the path's camera event.
+// trig = event_trig(u3, u2) of the event's uniforms (unused with the jitter off).
 template <typename R, typename ArgsT, typename CamPtr>
 __device__ __forceinline__ void camera_ray(const ArgsT& A, CamPtr camp, Ray<R>& ray,
-                                           uint32_t i, uint32_t j, const uint32_t rnd[4],
+                                           uint32_t i, uint32_t j, const uint32_t rnd[4], const EventTrig<R>& trig,
                                            float inv_w1, float inv_h1) {
   const auto& cam = *camp;
   R xi1 = (R)0.5, xi2 = (R)0.5;
@@ -994,10 +1020,8 @@ __device__ __forceinline__ void camera_ray(const ArgsT& A, CamPtr camp, Ray<R>& 
     xi1 = u01<R>(rnd[0]);
     xi2 = u01<R>(rnd[1]);
     // uniform point of the unit disk, scaled by the lens radius
-    R r = cam.lens_radius * M<R>::sqrt(u01<R>(rnd[2]));
-    R s, c;
-    M<R>::sincos2pi(u01<R>(rnd[3]), s, c);
-    offset = (r * c) * ld3<R>(cam.u) + (r * s) * ld3<R>(cam.v);
+    R r = cam.lens_radius * trig.rr;
+    offset = (r * trig.c) * ld3<R>(cam.u) + (r * trig.s) * ld3<R>(cam.v);
   }
   // main.scala:88-89 divides.  With the jitter off the division is kept: a reciprocal and a
   // multiply move pixel-centre rays across texel boundaries (24 of 2304 pixels of plane.json).
@@ -1266,15 +1290,19 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
       uint32_t rnd[4];
       philox4x32_10_keyed(pixel, sample, bounce, 0u, kernarg_args()->philox_keys, rnd);
       bool go = true;
+      // sine, cosine and square root for both kinds of event at once
+      const R z = scatter_z<R>(u01<R>(rnd[1]));
+      const EventTrig<R> trig = event_trig<R>(camera ? u01<R>(rnd[3]) : u01<R>(rnd[0]),
+                                              camera ? u01<R>(rnd[2]) : (R)1 - z * z);
       if (camera) {
         {
           const auto* ca = kernarg_args();
-          camera_ray<R, RenderArgs>(A, kernarg_camera<R>(), ray, cpx, cpy, rnd, ca->inv_w1, ca->inv_h1);
+          camera_ray<R, RenderArgs>(A, kernarg_camera<R>(), ray, cpx, cpy, rnd, trig, ca->inv_w1, ca->inv_h1);
         }
         T = mk<R>((R)1, (R)1, (R)1);
       } else {
         V3<R> dir;
-        go = scatter_direction<R>(sf, ray, rnd, dir, sc.L.scatter_diffuse_only != 0u);
+        go = scatter_direction<R>(sf, ray, rnd, trig, z, dir, sc.L.scatter_diffuse_only != 0u);
         ray.o = sf.p;
         ray.d = dir;
       }
@@ -1431,7 +1459,9 @@ __global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, Cam
   ra.H = A.H;
   const uint32_t no_rnd[4] = {0u, 0u, 0u, 0u};
   Ray<R> ray;
-  camera_ray<R, RenderArgs>(ra, &cam, ray, px, py, no_rnd, 0.f, 0.f);  // jitter off: pixel centre, lens closed
+  EventTrig<R> no_trig;
+  no_trig.s = no_trig.c = no_trig.rr = (R)0;
+  camera_ray<R, RenderArgs>(ra, &cam, ray, px, py, no_rnd, no_trig, 0.f, 0.f);  // jitter off: pixel centre, lens closed
   ray_setup<R>(ray);
   Trav<R> tv;
   trace_closest<R, WIDE>(sc, ray, tv, lds, stack_level0 + BT * RefT<WIDE>::STACK_ENTRY, (R)0.001);
@@ -1560,7 +1590,8 @@ __global__ void __launch_bounds__(256) wf_generate_kernel(WfArgs A, CamDev<float
   uint32_t rnd[4];
   philox4x32_10_keyed(pixel, sample, 0u, 0u, A.philox_keys, rnd);
   Ray<float> ray;
-  camera_ray<float, WfArgs>(A, &cam, ray, px, py, rnd, A.inv_w1, A.inv_h1);
+  camera_ray<float, WfArgs>(A, &cam, ray, px, py, rnd, event_trig<float>(u01<float>(rnd[3]), u01<float>(rnd[2])), A.inv_w1,
+                            A.inv_h1);
   const uint32_t cap = A.cap;
   A.cur.ray[slot] = ray.o.x; A.cur.ray[cap + slot] = ray.o.y; A.cur.ray[2u * cap + slot] = ray.o.z;
   A.cur.ray[3u * cap + slot] = ray.d.x; A.cur.ray[4u * cap + slot] = ray.d.y; A.cur.ray[5u * cap + slot] = ray.d.z;
@@ -1708,7 +1739,9 @@ __global__ void __launch_bounds__(1024) wf_shade_kernel(WfArgs A, CamDev<float> 
       uint32_t pixel, sample, rnd[4];
       wf_pixel_of(A, item, pixel, sample);
       philox4x32_10_keyed(pixel, sample, bounce, 0u, A.philox_keys, rnd);
-      go = scatter_direction<float>(sf, ray, rnd, dir, sc.L.scatter_diffuse_only != 0u);
+      const float z = scatter_z<float>(u01<float>(rnd[1]));
+      go = scatter_direction<float>(sf, ray, rnd, event_trig<float>(u01<float>(rnd[0]), 1.f - z * z), z, dir,
+                                    sc.L.scatter_diffuse_only != 0u);
     }
   }
   // compaction: the waves' survivor counts meet in LDS and one lane of the workgroup takes
