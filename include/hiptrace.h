@@ -193,6 +193,7 @@ typedef struct ht_stats {
   double shader_clock_mhz; /* in-kernel clock: s_memtime ticks per 100 MHz s_memrealtime tick */
   int32_t batch;          /* samples per pixel of a full launch as the library planned it   */
   int32_t kernel_sgprs;   /* scalar-register budget the chosen kernel is compiled to (80 / 96; 0: not capped) */
+  int64_t n_node_steps;   /* the part of n_steps offered by node steps (the rest: leaf steps)       */
   char kernel[64];        /* the path-tracing kernel the library chose for this scene, as a profiler
                              shows it: "render_kernel_8<4u>", "render_kernel_7<0u, true>",
                              "render_kernel<float, false, 1u, false>", or "wavefront"           */

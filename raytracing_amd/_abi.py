@@ -110,6 +110,7 @@ class ht_stats(C.Structure):
         ("shader_clock_mhz", C.c_double),
         ("batch", C.c_int32),
         ("kernel_sgprs", C.c_int32),
+        ("n_node_steps", C.c_int64),
         ("kernel", C.c_char * 64),
     ]
 

@@ -575,6 +575,7 @@ int render_accumulate_impl(ht_scene* s, const ht_camera* cam, const ht_render_pa
         stats->n_shade_rounds = (int64_t)h[CTR_SHADE_ROUNDS];
         stats->n_regen_rounds = (int64_t)h[CTR_REGEN_ROUNDS];
         stats->n_miss = (int64_t)h[CTR_MISS];
+        stats->n_node_steps = (int64_t)h[CTR_NODE_STEPS];
         stats->cyc_trav = (int64_t)h[CTR_CYC_TRAV];
         stats->cyc_shade = (int64_t)h[CTR_CYC_SHADE];
         stats->cyc_regen = (int64_t)h[CTR_CYC_REGEN];

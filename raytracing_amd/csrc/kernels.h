@@ -98,6 +98,7 @@ enum {
   CTR_SHADE0, CTR_SHADE1, CTR_SHADE2, CTR_SHADE3,
   CTR_TEX0, CTR_TEX1, CTR_TEX2, CTR_TEX3,
   CTR_STEPS, CTR_ACTIVE, CTR_SHADE_ROUNDS, CTR_REGEN_ROUNDS, CTR_MISS,
+  CTR_NODE_STEPS,                              // lane slots offered by node steps (the rest of CTR_STEPS: leaf steps)
   CTR_CYC_TRAV, CTR_CYC_SHADE, CTR_CYC_REGEN,  // wave cycles per phase (lane 0 of every wave)
   CTR_CLK_SHADER, CTR_CLK_REAL,  // s_memtime / s_memrealtime ticks of workgroup 0
   NUM_COUNTERS

@@ -1338,6 +1338,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
           if (CNT) cnt.v[CTR_ACTIVE]++;
         }
         if (CNT) cnt.v[CTR_STEPS]++;
+        if (CNT) cnt.v[CTR_NODE_STEPS]++;
         // a second step for the lanes that are still at inner nodes, without asking the
         // wave again: the ballots and counts of the loop head cost as much scalar issue
         // as half a node step
@@ -1346,6 +1347,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
           if (CNT) cnt.v[CTR_ACTIVE]++;
         }
         if (CNT) cnt.v[CTR_STEPS]++;
+        if (CNT) cnt.v[CTR_NODE_STEPS]++;
       }
       const bool leaf = (uint32_t)(tv.cur - RF::LEAF) < (RF::EMPTY - RF::LEAF);
       if (__ballot(leaf) != 0ull) {

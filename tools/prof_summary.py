@@ -15,7 +15,8 @@ for f in glob.glob(f"{base}/trace_{tag}/*/*_kernel_stats.csv"):
         print(f"{r['Name'][:90]:90s} calls={r['Calls']:>4s} total_ms={float(r['TotalDurationNs'])/1e6:10.3f} "
               f"avg_ms={float(r['AverageNs'])/1e6:9.4f} pct={float(r['Percentage']):6.2f}")
 print(f"\n## PMC passes (one rocprofv3 --pmc run each): bench.py --workload {wl} --steps 1 --warmup 0 --spp <samples per launch, default 1024> --no-cpu-baseline")
-print("## values are sums over the dispatches of the kernel in that run")
+print("## values are averages per dispatch of the kernel in that run (bench.py launches the production kernel once per")
+print("## step and once more for its statistics; the counters build, render_kernel<float, true, ..>, runs 64 spp once)")
 for n in (1, 2, 3, 4, 5, 6, 7, 8):
     for f in glob.glob(f"{base}/pmc{n}_{tag}/*/*_counter_collection.csv"):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -34,4 +35,4 @@ for n in (1, 2, 3, 4, 5, 6, 7, 8):
             print(f"pass {n}: {k[:70]} dispatches={len(disp[k])} vgpr={m[0]} agpr={m[1]} sgpr={m[2]} lds={m[3]} "
                   f"scratch={m[4]} wg={m[5]} grid={m[6]}")
             for c, x in sorted(v.items()):
-                print(f"    {c:28s} {x:.6g}")
+                print(f"    {c:28s} {x / len(disp[k]):.6g}")

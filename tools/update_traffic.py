@@ -20,7 +20,7 @@ base = os.path.join(ROOT, "gpurun_out", "prof")
 
 
 def counter(pass_no, name):
-    """Sum over the dispatches of the production render kernel (not the counters build)."""
+    """Average per dispatch of the production render kernel (not the counters build)."""
     tot = collections.defaultdict(float)
     files = glob.glob(f"{base}/pmc{pass_no}_{tag}/*/*_counter_collection.csv")
     # results of an earlier run with the same tag, merged into the same directory, would be summed in
@@ -30,8 +30,10 @@ def counter(pass_no, name):
             k = r["Kernel_Name"]
             if "render_kernel" in k and ", true," not in k and r["Counter_Name"] == name:
                 tot[r["Dispatch_Id"]] += float(r["Counter_Value"])
-    assert len(tot) == 1, f"expected one render launch in pass {pass_no}, found {len(tot)}"
-    return next(iter(tot.values()))
+    # bench.py launches the production kernel once per step and once more for its statistics: the
+    # same launch every time, so the figure per launch is the average over the dispatches
+    assert len(tot) >= 1, f"no render launch in pass {pass_no}"
+    return sum(tot.values()) / len(tot)
 
 
 path = os.path.join(ROOT, "profiles", "traffic.json")
