@@ -442,27 +442,32 @@ def main(argv=None):
             import numpy as np
             import ctypes as C
 
-            def host_call(want_linear):
+            def host_call(want_linear, calls=1):
                 p = ht.make_params(W, H, spp, seed=2025, batch=args.batch, device=local_rank, precision=precision)
-                rgb = np.zeros((H, W, 3), dtype=np.float32) if want_linear else None
-                pk = np.zeros((H, W), dtype=np.uint32)
+                # written once before the call so that the copy does not pay the caller's first-touch page faults
+                # (a renderFrame replacement fills the same BufferedImage array frame after frame)
+                rgb = np.full((H, W, 3), 0.5, dtype=np.float32) if want_linear else None
+                pk = np.full((H, W), 1, dtype=np.uint32)
                 cc = cam.to_c()
-                t0 = time.perf_counter()
-                rc = ht.load().ht_render(scene.handle, C.byref(cc), C.byref(p),
-                                         rgb.ctypes.data_as(A._pf32) if want_linear else None,
-                                         pk.ctypes.data_as(A._pu32), None)
-                dt = time.perf_counter() - t0
-                if rc != 0:
-                    raise RuntimeError(ht.load().ht_last_error().decode())
-                return total_samples / dt / 1e6
+                best = None
+                for _ in range(calls):
+                    t0 = time.perf_counter()
+                    rc = ht.load().ht_render(scene.handle, C.byref(cc), C.byref(p),
+                                             rgb.ctypes.data_as(A._pf32) if want_linear else None,
+                                             pk.ctypes.data_as(A._pu32), None)
+                    dt = time.perf_counter() - t0
+                    if rc != 0:
+                        raise RuntimeError(ht.load().ht_last_error().decode())
+                    best = dt if best is None else min(best, dt)
+                return total_samples / best / 1e6
 
             first_call = host_call(True)
             out["host_buffer_boundary"] = {
-                "value": host_call(False),
-                "value_with_linear_means": host_call(True),
+                "value": host_call(False, 3),
+                "value_with_linear_means": host_call(True, 3),
                 "value_first_call": first_call,
                 "unit": "Msamples/s",
-                "note": "ht_render into host memory, PCIe copies included; never the headline value.  value: the packed "
+                "note": "ht_render into host memory, PCIe copies included, best of 3 calls; never the headline value.  value: the packed "
                         "0x00RRGGBB picture only, which is all renderFrame's BufferedImage receives (main.scala:93); "
                         "value_with_linear_means: also the 12-byte-per-pixel float means; value_first_call: the call "
                         "that allocates the handle's cached device buffers"}

@@ -255,7 +255,7 @@ int launch_shape(ht_scene* s, int prec, bool counters, LaunchShape& out) {
   const int gen = g_shape_generation.load();
   if (c.generation != gen) {
     const SceneLayout& L = prec == HT_PRECISION_FP32 ? s->hs.layout32 : s->hs.layout64;
-    const uint32_t base_feat = s->feat | (L.tree_kinds == TREE_TRIANGLES ? KFEAT_TRIS : 0u);
+    const uint32_t base_feat = s->feat | (L.tree_kinds == TREE_TRIANGLES ? KFEAT_TRIS : 0u) | (L.n_nodes == 0u ? KFEAT_FLAT : 0u);
     LaunchShape best;
     const int forced = g_block_threads.load();
     // The production kernels are compiled to 96 scalar registers (seven waves per SIMD); the

@@ -51,8 +51,8 @@ def main():
                       f"{k.get('sgpr_spill_count', '?')} scalars in lanes, {k.get('vgpr_spill_count', '?')} VGPRs spilled")
                 if s > max_s or v > max_v:
                     bad.append(k["name"])
-    if seen < 7:
-        print(f"check_kernel_resources: found {seen} production kernels in {obj}, expected 7", file=sys.stderr)
+    if seen < 10:
+        print(f"check_kernel_resources: found {seen} production kernels in {obj}, expected 10", file=sys.stderr)
         return 1
     if bad:
         print("check_kernel_resources: over budget (launch_shape would promise waves that never run): " + ", ".join(bad),

@@ -115,6 +115,7 @@ uint32_t max_block_threads(int precision);
 constexpr uint32_t KFEAT_PERLIN = 1u, KFEAT_IMAGE = 2u;
 constexpr uint32_t KFEAT_TRIS = 4u;  // the hierarchy holds triangles only (used when no texture bit is set)
 constexpr uint32_t KFEAT_LEAN = 8u;  // the variant held to 80 scalar registers, eight waves per SIMD: fp32, on-chip store, plain textures
+constexpr uint32_t KFEAT_FLAT = 16u;  // the scene has no hierarchy: variants without a traversal phase where they exist
 
 // Number of workgroups of `threads` threads per CU the device can hold for this
 // kernel variant and LDS size (0: does not fit).

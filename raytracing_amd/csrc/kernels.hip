@@ -249,15 +249,24 @@ __device__ __forceinline__ uint32_t load_u32(const Scene& sc, uint32_t off, uint
 template <typename R>
 struct Ray {
   V3<R> o, d, inv;  // inv = 1/d per component
+  V3<R> oi;         // o * inv per component (fp32 box tests: (centre - o)/d as one fused multiply-add)
   R a, inv_a, oo;   // |d|^2, 1/|d|^2, |o|^2
 };
 
+// What only the sphere tests and the shading of a sphere read.  A kernel whose hierarchy holds
+// triangles alone works these out again before it shades, so that they hold no registers
+// during the traversal.
 template <typename R>
-__device__ __forceinline__ void ray_setup(Ray<R>& r) {
-  r.inv = mk<R>(M<R>::rcp(r.d.x), M<R>::rcp(r.d.y), M<R>::rcp(r.d.z));
+__device__ __forceinline__ void ray_sphere_terms(Ray<R>& r) {
   r.a = dot(r.d, r.d);
   r.inv_a = M<R>::rcp(r.a);
   r.oo = dot(r.o, r.o);
+}
+template <typename R>
+__device__ __forceinline__ void ray_setup(Ray<R>& r) {
+  r.inv = mk<R>(M<R>::rcp(r.d.x), M<R>::rcp(r.d.y), M<R>::rcp(r.d.z));
+  r.oi = mk<R>(r.o.x * r.inv.x, r.o.y * r.inv.y, r.o.z * r.inv.z);
+  ray_sphere_terms<R>(r);
 }
 
 template <typename R>
@@ -331,17 +340,18 @@ __device__ __forceinline__ bool slab(const Ray<R>& r, R lox, R loy, R loz, R hix
 //   fp64: (lo child 0, lo child 1, hi child 0, hi child 1);
 //   fp32: (centre 0, centre 1, half-extent 0, half-extent 1), the half-extent rounded up
 //         and widened by the host so that it also covers the rounding of this arithmetic.
-// With c = (centre - o)/d and e = half/|d| the slab is [c - e, c + e]: five adds and
-// multiplies per axis and child and no min/max to order the two planes (on gfx950 an
+// With c = (centre - o)/d = centre/d - o/d (one fused multiply-add, o/d kept with the ray; its
+// rounding is of the size of an ulp of the ray's own origin) and e = half/|d| the slab is
+// [c - e, c + e]: four operations per axis and child and no min/max to order the two planes (on gfx950 an
 // fp32 add or multiply issues in about half the cycles of a min, max, compare or select).
 template <typename R>
 __device__ __forceinline__ void slab2(const Ray<R>& r, const R b[12], R t_min, R t_far, R& tn0,
                                       R& tn1, bool& h0, bool& h1) {
   if constexpr (sizeof(R) == 4) {
     const float aix = __builtin_fabsf(r.inv.x), aiy = __builtin_fabsf(r.inv.y), aiz = __builtin_fabsf(r.inv.z);
-    const float cx0 = (b[0] - r.o.x) * r.inv.x, cx1 = (b[1] - r.o.x) * r.inv.x, ex0 = b[2] * aix, ex1 = b[3] * aix;
-    const float cy0 = (b[4] - r.o.y) * r.inv.y, cy1 = (b[5] - r.o.y) * r.inv.y, ey0 = b[6] * aiy, ey1 = b[7] * aiy;
-    const float cz0 = (b[8] - r.o.z) * r.inv.z, cz1 = (b[9] - r.o.z) * r.inv.z, ez0 = b[10] * aiz, ez1 = b[11] * aiz;
+    const float cx0 = __builtin_fmaf(b[0], r.inv.x, -r.oi.x), cx1 = __builtin_fmaf(b[1], r.inv.x, -r.oi.x), ex0 = b[2] * aix, ex1 = b[3] * aix;
+    const float cy0 = __builtin_fmaf(b[4], r.inv.y, -r.oi.y), cy1 = __builtin_fmaf(b[5], r.inv.y, -r.oi.y), ey0 = b[6] * aiy, ey1 = b[7] * aiy;
+    const float cz0 = __builtin_fmaf(b[8], r.inv.z, -r.oi.z), cz1 = __builtin_fmaf(b[9], r.inv.z, -r.oi.z), ez0 = b[10] * aiz, ez1 = b[11] * aiz;
     tn0 = __builtin_fmaxf(__builtin_fmaxf(cx0 - ex0, cy0 - ey0), __builtin_fmaxf(cz0 - ez0, t_min));
     tn1 = __builtin_fmaxf(__builtin_fmaxf(cx1 - ex1, cy1 - ey1), __builtin_fmaxf(cz1 - ez1, t_min));
     const float tf0 = __builtin_fminf(__builtin_fminf(cx0 + ex0, cy0 + ey0), cz0 + ez0);
@@ -622,7 +632,7 @@ __device__ __forceinline__ void node_step(const Scene& sc, const Ray<R>& ray, Tr
 
 // Start of a ray: the hoisted primitives (the same primitive for every lane, so
 // the wave runs one code path), then the bounds of the hierarchy.
-template <typename R, bool CNT, bool WIDE>
+template <typename R, bool CNT, bool WIDE, bool FLAT = false>
 __device__ __forceinline__ void ray_start(const Scene& sc, const Ray<R>& ray, Trav<R>& tv,
                                           uint32_t stack_level1, R t_min, Cnt& cnt) {
   trav_begin<R, WIDE>(tv, stack_level1);
@@ -632,7 +642,7 @@ __device__ __forceinline__ void ray_start(const Scene& sc, const Ray<R>& ray, Tr
     prim_test<R, CNT, WIDE>(sc, ray, tv, ref, t_min, cnt);
   }
   tv.cur = RefT<WIDE>::EMPTY;
-  if (sc.L.n_nodes != 0u) {
+  if (!FLAT && sc.L.n_nodes != 0u) {
     const R* rb = (const R*)(sc.base + sc.L.root_box);
     R tn;
     if (CNT) cnt.v[CTR_BOX]++;
@@ -800,6 +810,9 @@ constexpr uint32_t FEAT_PERLIN = 1u, FEAT_IMAGE = 2u;
 // Not a texture kind: the hierarchy holds triangles only (a mesh scene), known when the
 // kernel is compiled, so a leaf step has no dispatch on the kind of primitive at all.
 constexpr uint32_t FEAT_TRIS = 4u;
+// The scene has no hierarchy (every primitive is hoisted and tested when a ray starts): the
+// kernel has no traversal phase, no stacks and keeps no traversal state in registers.
+constexpr uint32_t FEAT_FLAT = 16u;
 
 template <typename R, bool CNT, uint32_t FEAT>
 __device__ __forceinline__ V3<R> texture_eval(const Scene& sc, const uint32_t* __restrict__ texels,
@@ -1105,6 +1118,7 @@ template <typename R, bool CNT, uint32_t FEAT, bool WIDE>
 __device__ __forceinline__ void render_body(const RenderArgs& A) {
   extern __shared__ __align__(16) uint8_t lds[];
   typedef RefT<WIDE> RF;
+  constexpr bool FLAT = (FEAT & FEAT_FLAT) != 0u;  // no hierarchy: a ray is finished when it starts
   const uint32_t BT = blockDim.x;  // <= M<R>::BT, a multiple of 64
   Scene sc;
   sc.L = A.L;
@@ -1150,10 +1164,11 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
   uint32_t state = ST_DEAD;
   uint32_t my_epoch = 0, pix = 0, pixel = 0, sample = 0, bounce = 0;
   ray.o = ray.d = ray.inv = mk<R>((R)0, (R)0, (R)0);
+  ray.oi = mk<R>((R)0, (R)0, (R)0);
   ray.a = ray.inv_a = ray.oo = (R)0;
   trav_begin<R, WIDE>(tv, stack_level1);
   tv.cur = RF::EMPTY;
-  stack_store<WIDE>(lds, stack_level0, RF::EMPTY);
+  if constexpr (!FLAT) stack_store<WIDE>(lds, stack_level0, RF::EMPTY);
 
   // adds the wave's tile sums to the frame and clears them
   auto flush_tile = [&]() {
@@ -1175,7 +1190,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
     // ---- 1. shade the finished rays: deposit, or prepare a scatter ------------------
     // A lane leaves this block as DEAD (path ended) or with `scatter` set.
     if (CNT) {
-      const uint64_t w = __ballot(state == ST_LIVE && tv.cur == RF::EMPTY);
+      const uint64_t w = __ballot(state == ST_LIVE && (FLAT || tv.cur == RF::EMPTY));
       if (lane == 0 && w != 0ull) cnt.v[CTR_SHADE_ROUNDS]++;
     }
     bool scatter = false;
@@ -1184,7 +1199,8 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
     sf.param = (R)0;
     sf.mkind = 0u;
     sf.front = false;
-    if (state == ST_LIVE && tv.cur == RF::EMPTY) {
+    if (state == ST_LIVE && (FLAT || tv.cur == RF::EMPTY)) {
+      if constexpr ((FEAT & FEAT_TRIS) != 0u && sizeof(R) == 4) ray_sphere_terms<R>(ray);
       Sink sink;
       sink.lds = tile_acc + pix * 3u;
       sink.global = frame + (size_t)pixel * 3u;
@@ -1309,7 +1325,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
       if (go) {
         bounce++;
         ray_setup<R>(ray);
-        ray_start<R, CNT, WIDE>(sc, ray, tv, stack_level1, t_min, cnt);
+        ray_start<R, CNT, WIDE, FLAT>(sc, ray, tv, stack_level1, t_min, cnt);
         state = ST_LIVE;
         if (CNT) cnt.v[CTR_RAYS]++;
       }  // else: absorbed, the lane stays DEAD and claims new work next round
@@ -1325,6 +1341,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
     if (__ballot(state != ST_DONE) == 0ull) break;  // the queue is empty and every path ended
     // ---- 4. traversal: node steps while most lanes are at inner nodes, then one leaf
     //         step for the lanes that reached a primitive; until enough rays are done ----
+    if constexpr (FLAT) continue;
     const int n_live = __popcll(__ballot(state == ST_LIVE));
     while (__ballot(tv.cur != RF::EMPTY) != 0ull) {
       for (;;) {
@@ -1630,6 +1647,7 @@ wf_trace_kernel(WfArgs A) {
   Cnt cnt;
   Ray<float> ray;
   ray.o = ray.d = ray.inv = mk<float>(0.f, 0.f, 0.f);
+  ray.oi = mk<float>(0.f, 0.f, 0.f);
   ray.a = ray.inv_a = ray.oo = 0.f;
   Trav<float> tv;
   trav_begin<float, WIDE>(tv, stack_level1);
@@ -1867,18 +1885,27 @@ int kernel_tier(int precision, bool counters, uint32_t feat, bool wide) {
   if (precision != 0 || counters) return 0;
   const uint32_t tex = feat & 3u;
   if (tex == 0u) return ((feat & KFEAT_LEAN) && !wide) ? 8 : 7;
+  if (tex == 1u && (feat & FEAT_FLAT) && !(feat & FEAT_TRIS) && !wide) return 7;  // Perlin textures, no hierarchy
   return (tex == 2u && !wide) ? 7 : 0;
+}
+// the variants without a traversal phase: on-chip store (a scene without a hierarchy is small)
+bool flat_variant(int precision, bool counters, uint32_t feat, bool wide) {
+  return (feat & FEAT_FLAT) != 0u && (feat & FEAT_TRIS) == 0u && precision == 0 && !counters && !wide;
 }
 RenderKernel32 tier_kernel(int tier, uint32_t feat, bool wide) {
   const bool tris = (feat & FEAT_TRIS) != 0u;
-  if (tier == 8) return tris ? render_kernel_8<FEAT_TRIS> : render_kernel_8<0>;
-  if ((feat & 3u) == 2u) return render_kernel_7<2u, false>;
+  const bool flat = flat_variant(0, false, feat, wide);
+  if (tier == 8) return flat ? render_kernel_8<FEAT_FLAT> : (tris ? render_kernel_8<FEAT_TRIS> : render_kernel_8<0>);
+  if ((feat & 3u) == 2u) return flat ? render_kernel_7<2u | FEAT_FLAT, false> : render_kernel_7<2u, false>;
+  if ((feat & 3u) == 1u) return render_kernel_7<1u | FEAT_FLAT, false>;  // kernel_tier() grants this to flat scenes only
   if (wide) return tris ? render_kernel_7<FEAT_TRIS, true> : render_kernel_7<0, true>;
   return tris ? render_kernel_7<FEAT_TRIS, false> : render_kernel_7<0, false>;
 }
 const void* render_kernel_ptr(int precision, bool counters, uint32_t feat, bool wide) {
   const int tier = kernel_tier(precision, counters, feat, wide);
   if (tier) return reinterpret_cast<const void*>(tier_kernel(tier, feat, wide));
+  if (flat_variant(precision, counters, feat, wide) && (feat & 3u) == 3u)  // Perlin and image textures, no hierarchy
+    return reinterpret_cast<const void*>((RenderKernel32)render_kernel<float, false, 3u | FEAT_FLAT, false>);
   return precision == 0 ? reinterpret_cast<const void*>(k32[wide ? 1 : 0][counters ? 1 : 0][feat_index(feat)])
                         : reinterpret_cast<const void*>(k64[wide ? 1 : 0][counters ? 1 : 0][feat_index(feat)]);
 }
@@ -1897,7 +1924,9 @@ int render_max_waves_per_cu(int precision, bool counters, uint32_t feat, bool wi
 // the scalar-register budget it is compiled to (0: the generic template, not capped).
 int render_kernel_name(int precision, bool counters, uint32_t feat, bool wide, char* out, size_t n) {
   const int tier = kernel_tier(precision, counters, feat, wide);
-  const unsigned f = (feat & 3u) == 0u && (feat & FEAT_TRIS) ? FEAT_TRIS : (feat & 3u);
+  const bool flat = flat_variant(precision, counters, feat, wide);
+  unsigned f = (feat & 3u) == 0u && (feat & FEAT_TRIS) ? FEAT_TRIS : (feat & 3u);
+  if (flat && (tier == 8 || (tier == 7 && f != 0u) || (tier == 0 && f == 3u))) f |= FEAT_FLAT;
   if (tier == 8) {
     snprintf(out, n, "render_kernel_8<%uu>", f);
     return 80;
