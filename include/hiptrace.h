@@ -374,7 +374,8 @@ int ht_scene_get_info(const ht_scene* scene, ht_scene_info* out);
 
 /* Process-wide tuning knobs of the device path (no counterpart in the reference):
  *   "wait_threshold"    lanes of a wave that may wait for shading before
- *                       traversal yields (1..64)
+ *                       traversal yields (1..64; 0, the default: 40 for the on-chip store, 32
+ *                       for the HBM store)
  *   "max_blocks_per_cu" cap on resident workgroups per compute unit
  *   "max_waves_per_cu"  cap on resident waves per compute unit (4..32; 0, the default: what the
  *                       kernel variant's scalar registers admit, 28 or 32; the occupancy query

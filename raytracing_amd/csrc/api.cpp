@@ -119,7 +119,7 @@ int fail(int code, const char* fmt, ...) {
   }
 
 // tuning knobs (ht_set_option)
-std::atomic<int> g_wait_threshold{40};
+std::atomic<int> g_wait_threshold{0};  // 0: by store (40 on chip, 32 in HBM, where a waiting lane costs less than a late round)
 std::atomic<int> g_max_blocks_per_cu{8};
 std::atomic<int> g_max_waves_per_cu{0};  // 0: what the kernel variant admits
 std::atomic<int> g_block_threads{0};  // 0: choose
@@ -349,6 +349,7 @@ int make_plan(ht_scene* s, const ht_camera* cam, const ht_render_params* p, int6
     a.philox_keys[2 * r + 1] = a.seed_hi + r * 0xBB67AE85u;
   }
   a.wait_threshold = g_wait_threshold.load();
+  if (a.wait_threshold <= 0) a.wait_threshold = a.L.wide ? 32 : 40;
   a.node_den = g_node_den.load();
   a.wait_ratio_num = g_wait_num.load();
   a.wait_ratio_den = g_wait_den.load();
@@ -628,7 +629,7 @@ const char* ht_last_error(void) { return g_error; }
 
 int ht_set_option(const char* name, int value) {
   if (!name) return fail(HT_E_INVALID, "option name is NULL");
-  if (!strcmp(name, "wait_threshold")) { g_wait_threshold = std::min(64, std::max(1, value)); return HT_OK; }
+  if (!strcmp(name, "wait_threshold")) { g_wait_threshold = std::min(64, std::max(0, value)); return HT_OK; }
   if (!strcmp(name, "max_waves_per_cu")) { g_max_waves_per_cu = value <= 0 ? 0 : std::min(32, std::max(4, value)); g_shape_generation++; return HT_OK; }
   if (!strcmp(name, "max_blocks_per_cu")) { g_max_blocks_per_cu = std::max(1, value); g_shape_generation++; return HT_OK; }
   if (!strcmp(name, "default_batch")) { g_default_batch = std::max(1, value); return HT_OK; }

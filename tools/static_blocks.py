@@ -4,7 +4,8 @@ kernels.hip, the copy is compiled to assembly, and the instructions between mark
 issue class (the classes of tools/microbench: fast ~2.3 cycles, normal ~4.1, transcendental ~8.2,
 64-bit multiply ~5).  Markers are `asm volatile` comments: the compiler keeps them in order but may
 move a few independent vector instructions across them.
-  python tools/static_blocks.py > profiles/r03_static_blocks.txt"""
+  python tools/static_blocks.py > profiles/r03_static_blocks.txt
+  python tools/static_blocks.py --dump NODE_STEPS_x2      (the instructions of one phase)"""
 import collections, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = open(os.path.join(ROOT, "raytracing_amd/csrc/kernels.hip")).read()
@@ -37,6 +38,11 @@ marks = [(0, "PROLOGUE")] + [(i, l.split("MARK_")[1].strip()) for i, l in enumer
 FAST = {"v_add_f32", "v_sub_f32", "v_mul_f32", "v_fmac_f32", "v_fma_f32", "v_mov_b32", "v_and_b32", "v_or_b32", "v_xor_b32",
         "v_add_u32", "v_sub_u32", "v_lshrrev_b32", "v_subrev_f32", "v_subrev_u32", "v_not_b32", "v_xor3_b32"}
 TRANS = {"v_rcp_f32", "v_sqrt_f32", "v_rsq_f32", "v_sin_f32", "v_cos_f32", "v_exp_f32", "v_log_f32", "v_rcp_iflag_f32"}
+if len(sys.argv) > 2 and sys.argv[1] == "--dump":  # the instructions of one phase
+    for (a, name), (b, _) in zip(marks, marks[1:]):
+        if name == sys.argv[2]:
+            print("\n".join(l for l in lines[a:b] if l.strip() and not l.strip().startswith((";", "."))))
+    sys.exit(0)
 print("render_kernel_8<4u>, static instructions per phase (VALU by issue class, estimated issue cycles of one pass)")
 print(f"{'phase':22s} {'VALU':>5s} {'fast':>5s} {'norm':>5s} {'trans':>5s} {'mad64':>5s} {'lane':>5s} {'~cyc':>6s} | {'SALU':>5s} {'brch':>5s} {'LDS':>4s} {'VMEM':>4s}")
 for (a, name), (b, _) in zip(marks, marks[1:]):
