@@ -442,12 +442,15 @@ def main(argv=None):
             import numpy as np
             import ctypes as C
 
-            def host_call(want_linear, calls=1):
+            def host_call(want_linear, calls=1, pinned=False):
                 p = ht.make_params(W, H, spp, seed=2025, batch=args.batch, device=local_rank, precision=precision)
                 # written once before the call so that the copy does not pay the caller's first-touch page faults
                 # (a renderFrame replacement fills the same BufferedImage array frame after frame)
                 rgb = np.full((H, W, 3), 0.5, dtype=np.float32) if want_linear else None
                 pk = np.full((H, W), 1, dtype=np.uint32)
+                if pinned:  # page-locked caller memory: the copy runs at the link's rate, without staging
+                    keep = torch.ones((H, W), dtype=torch.int32).pin_memory()
+                    pk = keep.numpy().view(np.uint32)
                 cc = cam.to_c()
                 best = None
                 for _ in range(calls):
@@ -465,11 +468,13 @@ def main(argv=None):
             out["host_buffer_boundary"] = {
                 "value": host_call(False, 3),
                 "value_with_linear_means": host_call(True, 3),
+                "value_into_pinned_memory": host_call(False, 3, pinned=True),
                 "value_first_call": first_call,
                 "unit": "Msamples/s",
                 "note": "ht_render into host memory, PCIe copies included, best of 3 calls; never the headline value.  value: the packed "
                         "0x00RRGGBB picture only, which is all renderFrame's BufferedImage receives (main.scala:93); "
-                        "value_with_linear_means: also the 12-byte-per-pixel float means; value_first_call: the call "
+                        "value_with_linear_means: also the 12-byte-per-pixel float means; value_into_pinned_memory: the packed picture into "
+                        "page-locked memory of the caller's; value_first_call: the call "
                         "that allocates the handle's cached device buffers"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(flat, cam, W, H)
