@@ -132,6 +132,7 @@ std::atomic<int> g_force_hbm{0};     // scenes created while set keep their imag
 std::atomic<int> g_wavefront{0};      // 1: fp32 renders run the wavefront variant
 std::atomic<int> g_wavefront_cap{1 << 24};  // paths in flight of the wavefront variant
 std::atomic<int> g_wavefront_refill{32};    // idle lanes of a trace wave that trigger a refill
+std::atomic<int> g_bvh_optimise_max_nodes{1 << 13};  // largest hierarchy (inner nodes) the optimiser is run over
 std::atomic<int> g_bvh_optimise{4};        // passes of the hierarchy optimiser over a new scene's hierarchy (0: off)
 std::atomic<int> g_timeline{0};            // 1: render launches record when their waves fetch units and end
 std::atomic<int> g_shape_generation{0};  // bumped by the options a launch shape depends on
@@ -639,6 +640,7 @@ int ht_set_option(const char* name, int value) {
   if (!strcmp(name, "node_den")) { g_node_den = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "wait_ratio_num")) { g_wait_num = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "wait_ratio_den")) { g_wait_den = std::max(1, value); return HT_OK; }
+  if (!strcmp(name, "bvh_optimise_max_nodes")) { g_bvh_optimise_max_nodes = std::max(0, value); return HT_OK; }
   if (!strcmp(name, "bvh_optimise")) { g_bvh_optimise = std::min(64, std::max(0, value)); return HT_OK; }
   if (!strcmp(name, "timeline")) { g_timeline = value ? 1 : 0; return HT_OK; }
   if (!strcmp(name, "gpu_bvh")) { g_gpu_bvh_min = std::max(0, value); return HT_OK; }
@@ -713,6 +715,7 @@ int ht_scene_create(const ht_scene_desc* desc, int device, ht_scene** out) {
     opt.external_ctx = &device;
     opt.external_min_prims = g_gpu_bvh_min.load();
     opt.optimise_passes = g_bvh_optimise.load();
+    opt.optimise_max_nodes = g_bvh_optimise_max_nodes.load();
     rc = build_host_scene(desc, s->hs, err, opt);
   } catch (const std::exception& e) {
     delete s;

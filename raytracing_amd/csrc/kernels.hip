@@ -283,26 +283,32 @@ struct Trav {
 // halves followed by their third bytes: with 4-byte entries a hierarchy of 17 levels takes
 // 100 bytes of LDS per lane (tile sums included) and six 256-thread workgroups fill a CU, at
 // three bytes 81 and seven (packing and the second LDS access cost 3 % at equal occupancy).
-// `addr` is the byte address of the lane's low half.
+// `addr` is the LDS byte address of the lane's low half.
+// Stack addresses are LDS byte addresses, not offsets from the workgroup's dynamic LDS: the base
+// (a link-time constant, zero in these kernels) is added once when a lane's level-0 address is
+// worked out, not by a vector add in front of every stack access.
+typedef __attribute__((address_space(3))) uint8_t LdsU8;
+typedef __attribute__((address_space(3))) uint16_t LdsU16;
+__device__ __forceinline__ uint32_t lds_address(const void* p) { return (uint32_t)(uintptr_t)(const LdsU8*)p; }
 template <bool WIDE>
 __device__ __forceinline__ uint32_t stack_hi_offset() {  // from a lane's low half to its third byte
   return WIDE ? 2u * blockDim.x - threadIdx.x : 0u;
 }
 template <bool WIDE>
-__device__ __forceinline__ uint32_t stack_load(const uint8_t* lds, uint32_t addr) {
-  const uint32_t lo = *(const uint16_t*)(lds + addr);
+__device__ __forceinline__ uint32_t stack_load(const uint8_t*, uint32_t addr) {
+  const uint32_t lo = *(const LdsU16*)(uintptr_t)addr;
   if constexpr (!WIDE) return lo;
-  const uint32_t c = lo | ((uint32_t)lds[addr + stack_hi_offset<WIDE>()] << 16);
+  const uint32_t c = lo | ((uint32_t)*(const LdsU8*)(uintptr_t)(addr + stack_hi_offset<WIDE>()) << 16);
   return (c & 0xFFFFFu) | ((c & 0xF00000u) << 8);
 }
 template <bool WIDE>
-__device__ __forceinline__ void stack_store(uint8_t* lds, uint32_t addr, uint32_t ref) {
+__device__ __forceinline__ void stack_store(uint8_t*, uint32_t addr, uint32_t ref) {
   if constexpr (!WIDE) {
-    *(uint16_t*)(lds + addr) = (uint16_t)ref;
+    *(LdsU16*)(uintptr_t)addr = (uint16_t)ref;
   } else {
     const uint32_t c = (ref & 0xFFFFFu) | ((ref >> 8) & 0xF00000u);
-    *(uint16_t*)(lds + addr) = (uint16_t)c;
-    lds[addr + stack_hi_offset<WIDE>()] = (uint8_t)(c >> 16);
+    *(LdsU16*)(uintptr_t)addr = (uint16_t)c;
+    *(LdsU8*)(uintptr_t)(addr + stack_hi_offset<WIDE>()) = (uint8_t)(c >> 16);
   }
 }
 
@@ -1131,7 +1137,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
     lds_image = A.L.total_bytes;
   }
   // the lane's stack: level 0 (holds REF_EMPTY) and level 1, as byte offsets into lds
-  const uint32_t stack_level0 = lds_image + threadIdx.x * 2u;
+  const uint32_t stack_level0 = lds_address(lds) + lds_image + threadIdx.x * 2u;
   const uint32_t stack_level1 = stack_level0 + BT * RF::STACK_ENTRY;
   const uint32_t lane = threadIdx.x & 63u;
   unsigned long long* tile_acc = (unsigned long long*)(lds + lds_image + stack_bytes(BT, A.L.depth, WIDE ? 1u : 0u) +
@@ -1460,7 +1466,7 @@ __global__ void __launch_bounds__(M<R>::BT) first_hit_kernel(FirstHitArgs A, Cam
     sc.base = lds;
     lds_image = A.L.total_bytes;
   }
-  const uint32_t stack_level0 = lds_image + threadIdx.x * 2u;
+  const uint32_t stack_level0 = lds_address(lds) + lds_image + threadIdx.x * 2u;
   stack_store<WIDE>(lds, stack_level0, RefT<WIDE>::EMPTY);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t tiles_x = (uint32_t)(A.W + TILE_W - 1) / TILE_W;
@@ -1638,7 +1644,7 @@ wf_trace_kernel(WfArgs A) {
     sc.base = lds;
     lds_image = A.L.total_bytes;
   }
-  const uint32_t stack_level0 = lds_image + threadIdx.x * 2u;
+  const uint32_t stack_level0 = lds_address(lds) + lds_image + threadIdx.x * 2u;
   const uint32_t stack_level1 = stack_level0 + BT * RF::STACK_ENTRY;
   stack_store<WIDE>(lds, stack_level0, RF::EMPTY);
   const uint32_t lane = threadIdx.x & 63u;
