@@ -262,9 +262,17 @@ __device__ __forceinline__ void ray_sphere_terms(Ray<R>& r) {
   r.inv_a = M<R>::rcp(r.a);
   r.oo = dot(r.o, r.o);
 }
-template <typename R>
+template <typename R, bool FLAT = false>  // FLAT: no hierarchy, so no box tests
 __device__ __forceinline__ void ray_setup(Ray<R>& r) {
   r.inv = mk<R>(M<R>::rcp(r.d.x), M<R>::rcp(r.d.y), M<R>::rcp(r.d.z));
+  if constexpr (sizeof(R) == 4 && !FLAT) {
+    // |1/d| is held to 1e30 (a direction component below 1e-30, zero included, counts as 1e-30:
+    // over any distance in a scene the ray does not move along that axis either way), so that
+    // o/d and centre/d stay finite and their difference means something: an infinite o/d beside a
+    // finite half-extent/|d| would put every box at minus infinity and end the ray without a hit
+    r.inv = mk<R>(__builtin_amdgcn_fmed3f(r.inv.x, -1e30f, 1e30f), __builtin_amdgcn_fmed3f(r.inv.y, -1e30f, 1e30f),
+                  __builtin_amdgcn_fmed3f(r.inv.z, -1e30f, 1e30f));
+  }
   r.oi = mk<R>(r.o.x * r.inv.x, r.o.y * r.inv.y, r.o.z * r.inv.z);
   ray_sphere_terms<R>(r);
 }
@@ -1330,7 +1338,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
       }
       if (go) {
         bounce++;
-        ray_setup<R>(ray);
+        ray_setup<R, FLAT>(ray);
         ray_start<R, CNT, WIDE, FLAT>(sc, ray, tv, stack_level1, t_min, cnt);
         state = ST_LIVE;
         if (CNT) cnt.v[CTR_RAYS]++;
