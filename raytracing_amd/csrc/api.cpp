@@ -336,7 +336,8 @@ int make_plan(ht_scene* s, const ht_camera* cam, const ht_render_params* p, int6
   // worse when a launch holds few of them per tile.  Measured on 1024-spp launches: 16 is
   // 1 % faster than 8 on the dragon and the Cornell box, 32 equals 8; on 256-spp launches 8 wins.
   const int launch_spp = std::min(p->batch > 0 ? p->batch : g_default_batch.load(), p->samples);
-  a.chunk = g_chunk.load() > 0 ? g_chunk.load() : (launch_spp >= 1024 ? 16 : 8);
+  // (a tile shard holds 1/tile_stride of the frame's units: it is sized like a launch of that many fewer samples)
+  a.chunk = g_chunk.load() > 0 ? g_chunk.load() : (launch_spp / std::max(1, (int)p->tile_stride) >= 1024 ? 16 : 8);
   a.chunk_tail = std::min(a.chunk, std::max(1, g_chunk_tail.load()));
   a.counters = pl.counters ? s->d_counters : nullptr;
   a.W = p->width;
