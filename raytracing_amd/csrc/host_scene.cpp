@@ -590,10 +590,23 @@ void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out, 
     n[1] = e1[2] * e2[0] - e1[0] * e2[2];
     n[2] = e1[0] * e2[1] - e1[1] * e2[0];
     uint32_t o = L.tri + i * 12 * RS;
+    // fp32 kernels take u and v from the hit point: the two middle vectors are the dual basis
+    // U = (e2 x n)/|n|^2, V = (n x e1)/|n|^2 there, the edges themselves for fp64
+    double s1[3] = {e1[0], e1[1], e1[2]}, s2[3] = {e2[0], e2[1], e2[2]};
+    if (sizeof(R) == 4) {
+      const double nn = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+      const double inv = nn > 0.0 ? 1.0 / nn : 0.0;  // a degenerate triangle is never hit (det = 0)
+      s1[0] = (e2[1] * n[2] - e2[2] * n[1]) * inv;
+      s1[1] = (e2[2] * n[0] - e2[0] * n[2]) * inv;
+      s1[2] = (e2[0] * n[1] - e2[1] * n[0]) * inv;
+      s2[0] = (n[1] * e1[2] - n[2] * e1[1]) * inv;
+      s2[1] = (n[2] * e1[0] - n[0] * e1[2]) * inv;
+      s2[2] = (n[0] * e1[1] - n[1] * e1[0]) * inv;
+    }
     for (int a = 0; a < 3; ++a) {
       bl.put<R>(o + a * RS, (R)d[a]);
-      bl.put<R>(o + (3 + a) * RS, (R)e1[a]);
-      bl.put<R>(o + (6 + a) * RS, (R)e2[a]);
+      bl.put<R>(o + (3 + a) * RS, (R)s1[a]);
+      bl.put<R>(o + (6 + a) * RS, (R)s2[a]);
       bl.put<R>(o + (9 + a) * RS, (R)n[a]);
     }
     bl.put<uint32_t>(L.meta_tri + i * 4, ((uint32_t)hs.prim_material[p] << META_MAT_SHIFT) | (uint32_t)p);

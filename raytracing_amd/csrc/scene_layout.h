@@ -112,7 +112,7 @@ struct SceneLayout {
   uint32_t sph;         // n_sph   * 4R   {cx, cy, cz, r}
   uint32_t sph_k;       // n_big   * R    K of the KIND_BIG_SPHERE entries, which come first in sph
   uint32_t rect;        // n_rect  * 8R   {a0, a1, b0, b1, k, -, -, -}
-  uint32_t tri;         // n_tri   * 12R  {A, e1 = B-A, e2 = C-A, n = e1 x e2}
+  uint32_t tri;         // n_tri   * 12R  {A, e1 = B-A, e2 = C-A, n = e1 x e2}; fp32: {A, (e2 x n)/|n|^2, (n x e1)/|n|^2, n}
   uint32_t meta_sph;    // n_sph   * u32
   uint32_t meta_rect;   // n_rect  * u32
   uint32_t meta_tri;    // n_tri   * u32
