@@ -380,6 +380,10 @@ int ht_scene_get_info(const ht_scene* scene, ht_scene_info* out);
  *   "max_waves_per_cu"  cap on resident waves per compute unit (4..32; 0, the default: what the
  *                       kernel variant's scalar registers admit, 28 or 32; the occupancy query
  *                       answers 32 for all)
+ *   "flat_kernels"      1 (default): a scene without a hierarchy (every primitive tested when a ray
+ *                       starts) runs a kernel variant compiled without the traversal phase; 0: the
+ *                       general variant (same sums; for comparing the two)
+ *   "bvh_optimise_max_nodes"  largest hierarchy (inner nodes) the optimiser is run over (8192)
  *   "block_threads"     force the workgroup size (multiple of 128; 0 = choose for occupancy)
  *   "node_den"          node steps continue while inner-node lanes * node_den >= travelling lanes
  *   "wait_ratio_num" / "wait_ratio_den"  traversal also yields to shading when

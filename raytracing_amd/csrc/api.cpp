@@ -133,6 +133,7 @@ std::atomic<int> g_wavefront{0};      // 1: fp32 renders run the wavefront varia
 std::atomic<int> g_wavefront_cap{1 << 24};  // paths in flight of the wavefront variant
 std::atomic<int> g_wavefront_refill{32};    // idle lanes of a trace wave that trigger a refill
 std::atomic<int> g_bvh_optimise_max_nodes{1 << 13};  // largest hierarchy (inner nodes) the optimiser is run over
+std::atomic<int> g_flat_kernels{1};        // scenes without a hierarchy run the kernel variants without a traversal phase
 std::atomic<int> g_bvh_optimise{4};        // passes of the hierarchy optimiser over a new scene's hierarchy (0: off)
 std::atomic<int> g_timeline{0};            // 1: render launches record when their waves fetch units and end
 std::atomic<int> g_shape_generation{0};  // bumped by the options a launch shape depends on
@@ -256,7 +257,7 @@ int launch_shape(ht_scene* s, int prec, bool counters, LaunchShape& out) {
   const int gen = g_shape_generation.load();
   if (c.generation != gen) {
     const SceneLayout& L = prec == HT_PRECISION_FP32 ? s->hs.layout32 : s->hs.layout64;
-    const uint32_t base_feat = s->feat | (L.tree_kinds == TREE_TRIANGLES ? KFEAT_TRIS : 0u) | (L.n_nodes == 0u ? KFEAT_FLAT : 0u);
+    const uint32_t base_feat = s->feat | (L.tree_kinds == TREE_TRIANGLES ? KFEAT_TRIS : 0u) | (L.n_nodes == 0u && g_flat_kernels.load() ? KFEAT_FLAT : 0u);
     LaunchShape best;
     const int forced = g_block_threads.load();
     // The production kernels are compiled to 96 scalar registers (seven waves per SIMD); the
@@ -641,6 +642,7 @@ int ht_set_option(const char* name, int value) {
   if (!strcmp(name, "node_den")) { g_node_den = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "wait_ratio_num")) { g_wait_num = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "wait_ratio_den")) { g_wait_den = std::max(1, value); return HT_OK; }
+  if (!strcmp(name, "flat_kernels")) { g_flat_kernels = value ? 1 : 0; g_shape_generation++; return HT_OK; }
   if (!strcmp(name, "bvh_optimise_max_nodes")) { g_bvh_optimise_max_nodes = std::max(0, value); return HT_OK; }
   if (!strcmp(name, "bvh_optimise")) { g_bvh_optimise = std::min(64, std::max(0, value)); return HT_OK; }
   if (!strcmp(name, "timeline")) { g_timeline = value ? 1 : 0; return HT_OK; }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A bench.py record of every workload plus the fp64 dragon (run on the GPU box through gpurun).
-#   tools/bench_all.sh <round tag>
+#   tools/bench_all.sh <tag>
 set -o pipefail
 T=$1
 mkdir -p gpurun_out/bench_$T

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/prof.sh for several benchmarked workloads (run on the GPU box through gpurun).
-#   tools/prof_all.sh <round tag, e.g. r03> <workload:spp per launch> ...
+#   tools/prof_all.sh <tag> <workload:spp per launch> ...
 set -o pipefail
 T=$1; shift
 R=$GRAFT_REPO_ROOT
