@@ -46,11 +46,18 @@
 #define F_alignbit(i) "v_alignbit_b32 %" #i ", %" #i ", %8, 7"
 #define F_ldexp(i) "v_ldexp_f32 %" #i ", %" #i ", 1"
 #define F_cvtpk(i) "v_cvt_pkrtz_f16_f32 %" #i ", %" #i ", %8"
+#define F_cvtf16(i) "v_cvt_f32_f16 %" #i ", %" #i
+#define F_cvtf16hi(i) "v_cvt_f32_f16_sdwa %" #i ", %" #i " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"
+#define F_fmamix(i) "v_fma_mix_f32 %" #i ", %8, %9, %" #i " op_sel_hi:[1,0,0]"
+#define F_fmamixhi(i) "v_fma_mix_f32 %" #i ", %8, %9, %" #i " op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+#define F_fma3(i) "v_fma_f32 %" #i ", %8, %9, %" #i
+#define F_med3(i) "v_med3_f32 %" #i ", %" #i ", %8, %9"
 #define F_mac16(i) "v_pk_mul_f32 %" #i ", %" #i ", %8"
 KERNEL(mov, F_mov) KERNEL(xor_, F_xor) KERNEL(or_, F_or) KERNEL(addu, F_addu) KERNEL(subu, F_subu) KERNEL(lshl, F_lshl)
 KERNEL(lshr, F_lshr) KERNEL(bfe, F_bfe) KERNEL(add3, F_add3) KERNEL(andor, F_andor) KERNEL(fmac, F_fmac) KERNEL(mul24, F_mul24)
 KERNEL(mad24, F_mad24) KERNEL(cvtfu, F_cvtfu) KERNEL(cvtuf, F_cvtuf) KERNEL(floor_, F_floor) KERNEL(fract, F_fract) KERNEL(sin_, F_sin)
 KERNEL(rsq, F_rsq) KERNEL(addf, F_addf) KERNEL(mulf, F_mulf) KERNEL(maxf, F_maxf) KERNEL(add64, F_add64) KERNEL(addneg, F_addneg)
+KERNEL(cvtf16, F_cvtf16) KERNEL(cvtf16hi, F_cvtf16hi) KERNEL(fmamix, F_fmamix) KERNEL(fmamixhi, F_fmamixhi) KERNEL(fma3, F_fma3) KERNEL(med3, F_med3)
 KERNEL(mulhi, F_mulhi) KERNEL(perm, F_perm) KERNEL(alignbit, F_alignbit) KERNEL(ldexp_, F_ldexp) KERNEL(cvtpk, F_cvtpk)
 
 typedef void (*kfn)(float*, int, float);
@@ -75,7 +82,7 @@ int main() {
 #define R(NAME) run(#NAME, k_##NAME, d);
   for (int rep = 0; rep < 2; ++rep) {
     R(addf) R(mulf) R(maxf) R(add64) R(addneg) R(mov) R(xor_) R(or_) R(addu) R(subu) R(lshl) R(lshr) R(bfe) R(add3) R(andor) R(fmac)
-    R(mul24) R(mad24) R(cvtfu) R(cvtuf) R(floor_) R(fract) R(sin_) R(rsq) R(mulhi) R(perm) R(alignbit) R(ldexp_) R(cvtpk)
+    R(mul24) R(mad24) R(cvtfu) R(cvtuf) R(floor_) R(fract) R(sin_) R(rsq) R(mulhi) R(perm) R(alignbit) R(ldexp_) R(cvtpk) R(cvtf16) R(cvtf16hi) R(fmamix) R(fmamixhi) R(fma3) R(med3)
   }
   return 0;
 }
