@@ -299,12 +299,12 @@ int main(int argc, char** argv) {
     CHECK(L->n_nodes == hs.nodes.size() && L->depth == (uint32_t)hs.depth, "layout counts");
     CHECK(!force_hbm || L->wide, "forced HBM store not taken");
     if (L->wide) {
-      // a wide reference must survive the three-byte form the HBM store's traversal stack keeps:
-      // bits 31-28 and 19-0 only, and never the empty reference
+      // the HBM store's image holds references in 24 bits (wide_ref24): bits 31-28 and 19-0 of the
+      // builder's form only, and never the empty reference
       for (size_t i = 0; i < hs.nodes.size(); ++i)
         for (int c = 0; c < 2; ++c) {
           const uint32_t r = hs.nodes[i].child[c];
-          const uint32_t packed = (r & 0xFFFFFu) | ((r >> 8) & 0xF00000u);
+          const uint32_t packed = wide_ref24(r);
           CHECK(((packed & 0xFFFFFu) | ((packed & 0xF00000u) << 8)) == r && r != WREF_EMPTY, "node %zu child %d: %08x does not fit 24 bits", i, c, r);
         }
     }

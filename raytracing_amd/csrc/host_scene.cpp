@@ -494,7 +494,7 @@ void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out, 
   const uint32_t RS = sizeof(R);
   memset(&L, 0, sizeof L);
   L.wide = wide ? 1u : 0u;
-  auto ref_out = [wide](uint32_t r) { return wide ? r : narrow_ref(r); };
+  auto ref_out = [wide](uint32_t r) { return wide ? wide_ref24(r) : narrow_ref(r); };
   L.n_nodes = (uint32_t)hs.nodes.size();
   L.n_sph = (uint32_t)hs.sph.size();
   L.n_rect = (uint32_t)hs.rect.size();
@@ -546,8 +546,8 @@ void write_blob(const HostScene& hs, SceneLayout& L, std::vector<uint8_t>& out, 
       co = o + 12 * RS;
     }
     if (wide) {
-      bl.put<uint32_t>(co, n.child[0]);
-      bl.put<uint32_t>(co + 4, n.child[1]);
+      bl.put<uint32_t>(co, wide_ref24(n.child[0]));
+      bl.put<uint32_t>(co + 4, wide_ref24(n.child[1]));
     } else {
       bl.put<uint32_t>(co, narrow_ref(n.child[0]) | (narrow_ref(n.child[1]) << 16));
     }

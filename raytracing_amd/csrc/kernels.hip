@@ -286,11 +286,11 @@ struct Trav {
 };
 
 // The traversal stacks in LDS: one row per level, [level][thread], so that the lanes of a wave
-// never meet in a bank.  On-chip store: 16-bit entries.  HBM store: a reference has 24
-// significant bits (scene_layout.h) and an entry is three bytes, a row being the threads' low
+// never meet in a bank.  On-chip store: 16-bit entries.  HBM store: a reference is 24 bits
+// (scene_layout.h) and an entry is those three bytes, a row being the threads' low
 // halves followed by their third bytes: with 4-byte entries a hierarchy of 17 levels takes
 // 100 bytes of LDS per lane (tile sums included) and six 256-thread workgroups fill a CU, at
-// three bytes 81 and seven (packing and the second LDS access cost 3 % at equal occupancy).
+// three bytes 81 and seven (the second LDS access costs 3 % at equal occupancy).
 // `addr` is the LDS byte address of the lane's low half.
 // Stack addresses are LDS byte addresses, not offsets from the workgroup's dynamic LDS: the base
 // (a link-time constant, zero in these kernels) is added once when a lane's level-0 address is
@@ -306,18 +306,12 @@ template <bool WIDE>
 __device__ __forceinline__ uint32_t stack_load(const uint8_t*, uint32_t addr) {
   const uint32_t lo = *(const LdsU16*)(uintptr_t)addr;
   if constexpr (!WIDE) return lo;
-  const uint32_t c = lo | ((uint32_t)*(const LdsU8*)(uintptr_t)(addr + stack_hi_offset<WIDE>()) << 16);
-  return (c & 0xFFFFFu) | ((c & 0xF00000u) << 8);
+  return lo | ((uint32_t)*(const LdsU8*)(uintptr_t)(addr + stack_hi_offset<WIDE>()) << 16);
 }
 template <bool WIDE>
 __device__ __forceinline__ void stack_store(uint8_t*, uint32_t addr, uint32_t ref) {
-  if constexpr (!WIDE) {
-    *(LdsU16*)(uintptr_t)addr = (uint16_t)ref;
-  } else {
-    const uint32_t c = (ref & 0xFFFFFu) | ((ref >> 8) & 0xF00000u);
-    *(LdsU16*)(uintptr_t)addr = (uint16_t)c;
-    *(LdsU8*)(uintptr_t)(addr + stack_hi_offset<WIDE>()) = (uint8_t)(c >> 16);
-  }
+  *(LdsU16*)(uintptr_t)addr = (uint16_t)ref;
+  if constexpr (WIDE) *(LdsU8*)(uintptr_t)(addr + stack_hi_offset<WIDE>()) = (uint8_t)(ref >> 16);
 }
 
 template <typename R, bool WIDE>

@@ -24,6 +24,7 @@ namespace ht {
 //   inner node : index (< 0x8000)             index (< 0x80000000)
 //   leaf       : 0x8000 | kind << 12 | i      0x80000000 | kind << 28 | i
 //   empty      : 0xFFFF                       0xF00FFFFF
+// (the 32-bit form is the host builder's; the HBM store's image holds wide_ref24() of it)
 // (a wide reference has 24 significant bits: 31-28 and 19-0; an inner index is below 2^20
 // because a scene holds at most 2^20 primitives.  The traversal stack of the HBM store keeps
 // them as three bytes, RefT<true>::STACK_ENTRY.)
@@ -44,11 +45,15 @@ template <> struct RefT<false> {
   static constexpr uint32_t LEAF = REF_LEAF, EMPTY = REF_EMPTY, KIND_SHIFT = REF_KIND_SHIFT,
                             INDEX_MASK = REF_INDEX_MASK;
 };
+// HBM store: the image holds references in 24 bits, leaf bit 23, kind in 22-20, index in 19-0
+// (wide_ref24 of the builder's 32-bit form), so that a traversal-stack entry of three bytes is
+// the reference itself and needs no packing.
 template <> struct RefT<true> {
   static constexpr uint32_t STACK_ENTRY = 3;
-  static constexpr uint32_t LEAF = WREF_LEAF, EMPTY = WREF_EMPTY, KIND_SHIFT = WREF_KIND_SHIFT,
-                            INDEX_MASK = WREF_INDEX_MASK;
+  static constexpr uint32_t LEAF = 0x800000u, EMPTY = 0xFFFFFFu, KIND_SHIFT = 20, INDEX_MASK = 0xFFFFFu;
 };
+// 32-bit reference of the builder -> the 24-bit form of the HBM store's image
+inline uint32_t wide_ref24(uint32_t w) { return (w & 0xFFFFFu) | ((w >> 8) & 0xF00000u); }
 // 32-bit reference -> its 16-bit form (the host builds with 32-bit references)
 inline uint32_t narrow_ref(uint32_t w) {
   if (w == WREF_EMPTY) return REF_EMPTY;
