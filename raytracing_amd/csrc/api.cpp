@@ -311,6 +311,19 @@ struct RenderPlan {
   int batch = 0;
 };
 
+// The work queue of one launch of `count` samples (RenderArgs::q_*): what the kernel would otherwise
+// work out again with four divisions at every unit fetch.
+void plan_queue(RenderArgs& a, int count) {
+  const int tiles_x = (a.W + TILE_W - 1) / TILE_W, tiles_y = (a.H + TILE_H - 1) / TILE_H;
+  const int chunk = std::max(1, (int)a.chunk), chunk_tail = std::max(1, (int)a.chunk_tail);
+  a.q_tiles_x = (uint32_t)tiles_x;
+  a.q_tiles = tiles_owned((uint32_t)tiles_x * (uint32_t)tiles_y, (uint32_t)a.tile_first, (uint32_t)std::max(1, (int)a.tile_stride));
+  a.q_s_big = count > chunk ? (uint32_t)(count - chunk) : 0u;  // samples in full-size units
+  a.q_big = (a.q_s_big + chunk - 1) / chunk;
+  a.q_steps = a.q_big + ((uint32_t)count - a.q_s_big + chunk_tail - 1) / chunk_tail;
+  a.q_main = a.q_tiles * a.q_steps;
+}
+
 int make_plan(ht_scene* s, const ht_camera* cam, const ht_render_params* p, int64_t* accum_dev, RenderPlan& pl) {
   pl.prec = p->precision;
   pl.counters = p->collect_counters != 0;
@@ -388,6 +401,7 @@ hipError_t enqueue_launch(const RenderPlan& pl, uint32_t* queue_head, int first,
   a.sample_first = first;
   a.sample_count = count;
   a.tile_counter = queue_head;
+  plan_queue(a, count);
   // the queue head starts behind the units the waves take without asking: one per wave
   const int n_waves = pl.grid * (pl.shape.threads / 64);
   hipError_t e = hipMemsetD32Async((hipDeviceptr_t)queue_head, n_waves, QUEUE_SLOT_BYTES / 4, stream);

@@ -1250,22 +1250,9 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
           break;
         }
         if (epoch != 0u) flush_tile();
-        // The queue's geometry is worked out here, once per unit, from arguments read on
-        // the spot: as values kept over the whole kernel it held ten scalar registers.
+        // The queue's geometry comes from the host (RenderArgs::q_*) and is read here, once per unit,
+        // on the spot: as values kept over the whole kernel it held ten scalar registers.
         const auto* ca = kernarg_args();
-        const uint32_t tiles_x = (uint32_t)(ca->W + TILE_W - 1) / TILE_W;
-        const uint32_t tiles_y = (uint32_t)(ca->H + TILE_H - 1) / TILE_H;
-        // tile sharding: this launch owns every tile_stride-th tile from tile_first on
-        const uint32_t t_first = (uint32_t)ca->tile_first, t_stride = (uint32_t)ca->tile_stride;
-        const uint32_t n_tiles = t_first < tiles_x * tiles_y ? (tiles_x * tiles_y - t_first + t_stride - 1u) / t_stride : 0u;
-        // the last `chunk` samples of the launch are cut into units of `chunk_tail` samples:
-        // the units still running when the queue runs dry decide how long the launch drags on
-        const uint32_t chunk = (uint32_t)ca->chunk, chunk_tail = (uint32_t)ca->chunk_tail;
-        const uint32_t s_total = (uint32_t)ca->sample_count;
-        const uint32_t s_big = s_total > chunk ? s_total - chunk : 0u;        // samples in full-size units
-        const uint32_t n_big = (s_big + chunk - 1u) / chunk;
-        const uint32_t n_small = (s_total - s_big + chunk_tail - 1u) / chunk_tail;
-        const uint32_t n_units = n_tiles * (n_big + n_small);
         // A wave's first unit is its own number in the launch (the host starts the queue head at
         // the number of waves): thousands of waves asking one counter at the same moment would
         // be served one at a time.  Later units come from the counter.
@@ -1275,23 +1262,33 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
         // the unit's state lives in scalar registers and the loop branches on scalars
         unit = __builtin_amdgcn_readfirstlane(unit);
         if (ca->timeline != nullptr && lane == 0)  // profiling run: when units are fetched
-          atomicAdd(ca->timeline + (unit >= n_units ? TIMELINE_BINS : 0u) +
+          atomicAdd(ca->timeline + (unit >= ca->q_main ? TIMELINE_BINS : 0u) +
                         (((uint32_t)(__builtin_amdgcn_s_memrealtime() >> 10)) & (TIMELINE_BINS - 1u)), 1u);
-        if (unit >= n_units) {
+        if (unit >= ca->q_main) {
           queue_empty = true;
           epoch++;  // whatever is still in flight deposits to the frame directly
           continue;
         }
-        const uint32_t ck = unit / n_tiles, tile = t_first + (unit - ck * n_tiles) * t_stride;
-        tile_x0 = (tile % tiles_x) * TILE_W;
-        tile_y0 = (tile / tiles_x) * TILE_H;
-        uint32_t first, count;
-        if (ck < n_big) {
-          first = ck * chunk;
-          count = min(chunk, s_big - first);
-        } else {
-          first = s_big + (ck - n_big) * chunk_tail;
-          count = min(chunk_tail, s_total - first);
+        // Units are numbered step-major: step ck of the launch's own tiles, one after the other
+        // (tile sharding: every tile_stride-th tile from tile_first on).  The last `chunk` samples of
+        // the launch are cut into units of `chunk_tail` samples: the units still running when the
+        // queue runs dry decide how long the launch drags on.
+        uint32_t tile, first, count;
+        {
+          const uint32_t ck = unit / ca->q_tiles;
+          tile = (uint32_t)ca->tile_first + (unit - ck * ca->q_tiles) * (uint32_t)ca->tile_stride;
+          if (ck < ca->q_big) {
+            first = ck * (uint32_t)ca->chunk;
+            count = min((uint32_t)ca->chunk, ca->q_s_big - first);
+          } else {
+            first = ca->q_s_big + (ck - ca->q_big) * (uint32_t)ca->chunk_tail;
+            count = min((uint32_t)ca->chunk_tail, (uint32_t)ca->sample_count - first);
+          }
+        }
+        {
+          const uint32_t ty = tile / ca->q_tiles_x;
+          tile_x0 = (tile - ty * ca->q_tiles_x) * TILE_W;
+          tile_y0 = ty * TILE_H;
         }
         sample_base = (uint32_t)ca->sample_first + first;
         pool_size = TILE_PIXELS * count;
