@@ -118,6 +118,8 @@ def parse_args(argv=None):
                     help="frames in flight, each with its own buffers and HIP stream.  2 lets the drain of one frame "
                          "overlap the start of the next, but two resident persistent launches share the CUs badly: "
                          "measured 103.2 instead of 94.9 ms per dragon frame on one GPU, so 1 is the default")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
+                    help="a library option (ht_set_option) for this run, e.g. --set xcd_bands=0 (profiling A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the CPU baseline and the host-buffer leg (profiling runs)")
     ap.add_argument("--selftest-standin", action="store_true",
@@ -237,6 +239,9 @@ def main(argv=None):
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: libhiptrace has no CPU path")
+    for kv in args.set:
+        name, _, val = kv.partition("=")
+        ht.set_option(name, int(val))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ranks_seen = 1

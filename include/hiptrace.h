@@ -410,7 +410,11 @@ int ht_scene_get_info(const ht_scene* scene, ht_scene_info* out);
  *                       now on (default 4; 0: the hierarchy stays as the top-down builder made it)
  *   "timeline"          1: render launches record, per 10.24 us bin of the device's 100 MHz clock, how
  *                       many work units their waves fetched, how many waves found the queue empty and
- *                       how many ended (profiling; read with ht_debug_timeline) */
+ *                       how many ended (profiling; read with ht_debug_timeline)
+ *   "xcd_bands"         1 (default): a launch over a scene in the HBM store cuts its tiles into eight bands
+ *                       (rows of the picture) with a queue head each, and a wave takes its work from the
+ *                       band of the XCD it runs on, so that one part of the mesh stays in one XCD's L2;
+ *                       0: one queue for all.  Order of the work only: the sums are the same. */
 int ht_set_option(const char* name, int value);
 
 /* Profiling aid (no counterpart in the reference): the counters of the option "timeline" for the

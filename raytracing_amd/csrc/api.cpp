@@ -136,6 +136,7 @@ std::atomic<int> g_bvh_optimise_max_nodes{1 << 13};  // largest hierarchy (inner
 std::atomic<int> g_flat_kernels{1};        // scenes without a hierarchy run the kernel variants without a traversal phase
 std::atomic<int> g_bvh_optimise{4};        // passes of the hierarchy optimiser over a new scene's hierarchy (0: off)
 std::atomic<int> g_timeline{0};            // 1: render launches record when their waves fetch units and end
+std::atomic<int> g_xcd_bands{1};           // HBM store: a band of tiles and a queue head per XCD
 std::atomic<int> g_shape_generation{0};  // bumped by the options a launch shape depends on
 
 // Makes `device` current for the lifetime of the object, then restores.
@@ -311,19 +312,6 @@ struct RenderPlan {
   int batch = 0;
 };
 
-// The work queue of one launch of `count` samples (RenderArgs::q_*): what the kernel would otherwise
-// work out again with four divisions at every unit fetch.
-void plan_queue(RenderArgs& a, int count) {
-  const int tiles_x = (a.W + TILE_W - 1) / TILE_W, tiles_y = (a.H + TILE_H - 1) / TILE_H;
-  const int chunk = std::max(1, (int)a.chunk), chunk_tail = std::max(1, (int)a.chunk_tail);
-  a.q_tiles_x = (uint32_t)tiles_x;
-  a.q_tiles = tiles_owned((uint32_t)tiles_x * (uint32_t)tiles_y, (uint32_t)a.tile_first, (uint32_t)std::max(1, (int)a.tile_stride));
-  a.q_s_big = count > chunk ? (uint32_t)(count - chunk) : 0u;  // samples in full-size units
-  a.q_big = (a.q_s_big + chunk - 1) / chunk;
-  a.q_steps = a.q_big + ((uint32_t)count - a.q_s_big + chunk_tail - 1) / chunk_tail;
-  a.q_main = a.q_tiles * a.q_steps;
-}
-
 int make_plan(ht_scene* s, const ht_camera* cam, const ht_render_params* p, int64_t* accum_dev, RenderPlan& pl) {
   pl.prec = p->precision;
   pl.counters = p->collect_counters != 0;
@@ -401,10 +389,13 @@ hipError_t enqueue_launch(const RenderPlan& pl, uint32_t* queue_head, int first,
   a.sample_first = first;
   a.sample_count = count;
   a.tile_counter = queue_head;
-  plan_queue(a, count);
-  // the queue head starts behind the units the waves take without asking: one per wave
+  // HBM store: a band of tiles and a queue head per XCD (kernels.hip, the unit fetch)
+  a.q = plan_queue(a.W, a.H, (uint32_t)a.tile_first, (uint32_t)a.tile_stride, (uint32_t)count, (uint32_t)a.chunk,
+                   (uint32_t)a.chunk_tail, a.L.wide != 0u && g_xcd_bands.load() != 0);
+  // One queue (on-chip store): the head starts behind the units the waves take without asking,
+  // one per wave.  Banded queues: every head starts at zero.
   const int n_waves = pl.grid * (pl.shape.threads / 64);
-  hipError_t e = hipMemsetD32Async((hipDeviceptr_t)queue_head, n_waves, QUEUE_SLOT_BYTES / 4, stream);
+  hipError_t e = hipMemsetD32Async((hipDeviceptr_t)queue_head, a.L.wide ? 0 : n_waves, QUEUE_SLOT_BYTES / 4, stream);
   if (e == hipSuccess)
     e = launch_render(pl.prec, pl.counters, pl.kfeat, a, pl.camp, pl.grid, pl.shape.threads, pl.shape.lds, stream);
   return e;
@@ -652,6 +643,7 @@ int ht_set_option(const char* name, int value) {
   if (!strcmp(name, "default_batch")) { g_default_batch = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "chunk")) { g_chunk = std::max(0, value); return HT_OK; }
   if (!strcmp(name, "chunk_tail")) { g_chunk_tail = std::max(1, value); return HT_OK; }
+  if (!strcmp(name, "xcd_bands")) { g_xcd_bands = value != 0; return HT_OK; }
   if (!strcmp(name, "block_threads")) { g_block_threads = value; g_shape_generation++; return HT_OK; }
   if (!strcmp(name, "node_den")) { g_node_den = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "wait_ratio_num")) { g_wait_num = std::max(1, value); return HT_OK; }

@@ -3,6 +3,8 @@
 // AddressSanitizer + UBSan by `make build_check`; no device code, no HIP runtime.
 //
 //   build_check <n_spheres> <n_triangles> <n_rects> <seed> [force_hbm [external]]
+//   build_check queue <seed>    the work queue of a launch (work_queue.h): the planning the library does
+//                               and the numbering the kernels read a unit's tile and samples from
 // external: 1 = the hierarchy comes from a stand-in for the device builder (median splits),
 // 2 = from one that loses a primitive, 3 = from one that is a chain as deep as the scene;
 // 2 and 3 must be refused and the host's own hierarchy used.
@@ -17,6 +19,7 @@
 #include <vector>
 
 #include "host_scene.h"
+#include "work_queue.h"
 
 using namespace ht;
 
@@ -184,9 +187,78 @@ bool standin_builder(void* ctx, uint32_t n, const float* boxes, const float*, co
   return true;
 }
 
+// The work queue of launches of many shapes: fastdiv against the division it replaces, and every
+// (own tile, sample) of the launch handed out exactly once whichever way the units are drawn from
+// the one queue (on-chip store) or from the bands' queues (HBM store), as the kernels' unit fetch
+// numbers them.
+int check_queue(uint64_t seed) {
+  std::mt19937_64 rng(seed);
+  auto rnd = [&](uint32_t lo, uint32_t hi) { return lo + (uint32_t)(rng() % ((uint64_t)hi - lo + 1)); };
+  // fastdiv: small and large divisors, dividends around the multiples and at the ends of the range
+  for (int it = 0; it < 200000; ++it) {
+    const uint32_t d = it < 5000 ? (uint32_t)it + 1u : (it & 1 ? rnd(1, 1u << 20) : rnd(1, 0xFFFFFFFFu));
+    const FastDiv f = make_fastdiv(d);
+    const uint32_t mult = rnd(0, 0xFFFFFFFFu / d) * d;
+    const uint32_t ns[] = {0u, 1u, d - 1u, d, d + 1u, mult, mult - 1u, mult + 1u, 0xFFFFFFFFu, 0x7FFFFFFFu, rnd(0, 0xFFFFFFFFu)};
+    for (uint32_t n : ns) CHECK(fastdiv(n, f.m, f.sh) == n / d, "fastdiv(%u, %u) = %u", n, d, fastdiv(n, f.m, f.sh));
+  }
+  int launches = 0;
+  for (int it = 0; it < 300; ++it) {
+    const int32_t W = (int32_t)rnd(2, it % 7 == 0 ? 700 : 200), H = (int32_t)rnd(2, it % 5 == 0 ? 400 : 120);
+    const uint32_t stride = it % 3 == 0 ? rnd(1, 9) : 1u, first = rnd(0, stride - 1u);
+    const uint32_t samples = rnd(1, it % 4 == 0 ? 300 : 40), chunk = 1u << rnd(0, 4), chunk_tail = std::min(chunk, 1u << rnd(0, 3));
+    for (int banded = 0; banded < 2; ++banded) {
+      const QueueGeom q = plan_queue(W, H, first, stride, samples, chunk, chunk_tail, banded != 0);
+      const uint32_t tiles_x = (uint32_t)(W + 7) / 8u, tiles_y = (uint32_t)(H + 7) / 8u, n_tiles = tiles_x * tiles_y;
+      std::vector<uint32_t> seen((size_t)n_tiles * samples, 0u);
+      auto take = [&](uint32_t ck, uint32_t k) {  // what the kernel does with a unit
+        uint32_t f0 = 0, cnt = 0;
+        step_samples(ck, q.big, q.s_big, chunk, chunk_tail, samples, f0, cnt);
+        const uint32_t tile = first + k * stride;
+        const uint32_t ty = fastdiv(tile, q.div_tiles_x.m, q.div_tiles_x.sh), tx = tile - ty * q.tiles_x;
+        CHECK(tile < n_tiles && ty < tiles_y && tx < tiles_x && ty * tiles_x + tx == tile, "tile %u of %u", tile, n_tiles);
+        CHECK(f0 + cnt <= samples, "samples [%u, %u) of %u", f0, f0 + cnt, samples);
+        if (tile < n_tiles)
+          for (uint32_t s_ = f0; s_ < f0 + cnt && s_ < samples; ++s_) seen[(size_t)tile * samples + s_]++;
+      };
+      if (!banded) {
+        CHECK(q.bands == 1u, "one queue");
+        for (uint32_t unit = 0; unit < q.units; ++unit) {
+          const uint32_t ck = fastdiv(unit, q.div_tiles.m, q.div_tiles.sh);
+          take(ck, unit - ck * q.tiles);
+        }
+      } else {
+        CHECK(q.bands == (q.tiles >= 8u * QUEUE_BANDS ? QUEUE_BANDS : 1u), "bands");
+        uint32_t sum = 0;
+        for (uint32_t b = 0; b < q.bands; ++b) {
+          CHECK(q.band_start[b] == sum && q.band_units[b] == q.band_tiles[b] * q.steps, "band %u", b);
+          sum += q.band_tiles[b];
+          for (uint32_t u = 0; u < q.band_units[b]; ++u) {
+            const uint32_t ck = fastdiv(u, q.band_div[b].m, q.band_div[b].sh);
+            take(ck, q.band_start[b] + (u - ck * q.band_tiles[b]));
+          }
+        }
+        CHECK(sum == q.tiles, "the bands hold %u of %u tiles", sum, q.tiles);
+      }
+      size_t bad = 0;
+      for (uint32_t t = 0; t < n_tiles; ++t) {
+        const uint32_t want = (t >= first && (t - first) % stride == 0u) ? 1u : 0u;
+        for (uint32_t s_ = 0; s_ < samples; ++s_) bad += seen[(size_t)t * samples + s_] != want;
+      }
+      CHECK(bad == 0, "%zu (tile, sample) pairs not rendered exactly once: %dx%d first %u stride %u samples %u chunk %u/%u banded %d",
+            bad, W, H, first, stride, samples, chunk, chunk_tail, banded);
+      ++launches;
+    }
+  }
+  if (g_fail) return 1;
+  printf("ok queue launches=%d\n", launches);
+  return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
+  if (argc >= 3 && !strcmp(argv[1], "queue")) return check_queue((uint64_t)atoll(argv[2]));
   if (argc < 5) { fprintf(stderr, "usage: build_check n_spheres n_triangles n_rects seed [force_hbm]\n"); return 2; }
   const int ns = atoi(argv[1]), nt = atoi(argv[2]), nr = atoi(argv[3]);
   std::mt19937_64 rng((uint64_t)atoll(argv[4]));

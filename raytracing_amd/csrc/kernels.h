@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "scene_layout.h"
+#include "work_queue.h"
 
 namespace ht {
 
@@ -44,10 +45,7 @@ struct RenderArgs {
   int32_t tile_stride;     //   frame (row-major tile numbers); 0 / 1: every tile
   uint32_t* timeline;      // nullptr, or 3 x TIMELINE_BINS counters of a profiling run: work units fetched,
                            //   waves that found the queue empty, waves that ended, per time bin
-  // Geometry of the work queue, worked out by the host per launch (plan_queue in api.cpp).  A unit is
-  // (step, tile): q_steps steps over the launch's own q_tiles tiles, the first q_big steps of `chunk`
-  // samples (q_s_big samples in all), the others of `chunk_tail`; q_main = q_steps * q_tiles units.
-  uint32_t q_tiles_x, q_tiles, q_big, q_s_big, q_steps, q_main;
+  QueueGeom q;             // geometry of the work queue of this launch (work_queue.h)
 };
 // a timeline bin is 1024 ticks of the 100 MHz s_memrealtime clock (10.24 us); bin = (ticks >> 10) mod TIMELINE_BINS
 constexpr uint32_t TIMELINE_BINS = 4096;

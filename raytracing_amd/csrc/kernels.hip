@@ -1095,6 +1095,11 @@ __device__ __forceinline__ const __attribute__((address_space(4))) RenderArgs* k
   return (const __attribute__((address_space(4))) RenderArgs*)p;
 }
 
+// The XCD (accelerator complex die, 0-7) this wave runs on: HW_REG_XCC_ID (20), bits 3:0.
+__device__ __forceinline__ uint32_t xcc_id() {
+  return (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 15u;
+}
+
 // ---------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------
@@ -1175,6 +1180,10 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
   uint32_t next_item = 0, pool_size = 0;
   uint32_t tile_x0 = 0, tile_y0 = 0, sample_base = 0;
   bool queue_empty = false;
+  // HBM store: the band of tiles this wave takes its units from (that of its XCD to begin with) and
+  // the number of bands it has found used up
+  uint32_t band = 0, bands_done = 0;
+  if constexpr (WIDE) band = xcc_id() & (kernarg_args()->q.bands - 1u);
 
   // per-lane path state
   Ray<R> ray;
@@ -1250,44 +1259,70 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
           break;
         }
         if (epoch != 0u) flush_tile();
-        // The queue's geometry comes from the host (RenderArgs::q_*) and is read here, once per unit,
-        // on the spot: as values kept over the whole kernel it held ten scalar registers.
+        // The queue's geometry comes from the host (RenderArgs::q, work_queue.h) and is read here, once
+        // per unit, on the spot: as values kept over the whole kernel it held ten scalar registers,
+        // and worked out here it took four divisions.
         const auto* ca = kernarg_args();
-        // A wave's first unit is its own number in the launch (the host starts the queue head at
-        // the number of waves): thousands of waves asking one counter at the same moment would
-        // be served one at a time.  Later units come from the counter.
-        uint32_t unit = blockIdx.x * (BT >> 6) + (threadIdx.x >> 6);
-        if (epoch != 0u && lane == 0) unit = atomicAdd(ca->tile_counter, 1u);
-        // every lane is here (the loop's control is wave-uniform); read as a scalar, so that
-        // the unit's state lives in scalar registers and the loop branches on scalars
-        unit = __builtin_amdgcn_readfirstlane(unit);
-        if (ca->timeline != nullptr && lane == 0)  // profiling run: when units are fetched
-          atomicAdd(ca->timeline + (unit >= ca->q_main ? TIMELINE_BINS : 0u) +
-                        (((uint32_t)(__builtin_amdgcn_s_memrealtime() >> 10)) & (TIMELINE_BINS - 1u)), 1u);
-        if (unit >= ca->q_main) {
-          queue_empty = true;
-          epoch++;  // whatever is still in flight deposits to the frame directly
-          continue;
-        }
-        // Units are numbered step-major: step ck of the launch's own tiles, one after the other
-        // (tile sharding: every tile_stride-th tile from tile_first on).  The last `chunk` samples of
-        // the launch are cut into units of `chunk_tail` samples: the units still running when the
-        // queue runs dry decide how long the launch drags on.
-        uint32_t tile, first, count;
-        {
-          const uint32_t ck = unit / ca->q_tiles;
-          tile = (uint32_t)ca->tile_first + (unit - ck * ca->q_tiles) * (uint32_t)ca->tile_stride;
-          if (ck < ca->q_big) {
-            first = ck * (uint32_t)ca->chunk;
-            count = min((uint32_t)ca->chunk, ca->q_s_big - first);
-          } else {
-            first = ca->q_s_big + (ck - ca->q_big) * (uint32_t)ca->chunk_tail;
-            count = min((uint32_t)ca->chunk_tail, (uint32_t)ca->sample_count - first);
+        uint32_t ck = 0, k = 0;  // the unit: step ck of the launch's own tile number k
+        if constexpr (WIDE) {
+          // HBM store: the launch's own tiles are cut into bands of consecutive tiles (rows of the
+          // picture), each with a queue head of its own, and a wave takes units from the band of the
+          // XCD it runs on: the paths of one band meet one part of the mesh, which then stays in that
+          // XCD's L2 (4 MB each; they share nothing).  A wave whose band is used up goes on to the
+          // next, so the XCDs whose bands were cheap help with the others.  Which band a wave takes
+          // is a matter of speed only: every unit is handed out once, whatever the placement.
+          bool none_left = false;
+          for (;;) {
+            uint32_t u = 0;
+            if (lane == 0) u = atomicAdd(ca->tile_counter + band * QUEUE_BAND_WORDS, 1u);
+            u = __builtin_amdgcn_readfirstlane(u);
+            if (u < ca->q.band_units[band]) {
+              ck = fastdiv(u, ca->q.band_div[band].m, ca->q.band_div[band].sh);
+              k = ca->q.band_start[band] + (u - ck * ca->q.band_tiles[band]);
+              break;
+            }
+            // this band is used up (a head only grows): on to the next one
+            band = (band + 1u) & (ca->q.bands - 1u);
+            if (++bands_done >= ca->q.bands) {
+              none_left = true;
+              break;
+            }
           }
+          if (ca->timeline != nullptr && lane == 0)  // profiling run: when units are fetched
+            atomicAdd(ca->timeline + (none_left ? TIMELINE_BINS : 0u) +
+                          (((uint32_t)(__builtin_amdgcn_s_memrealtime() >> 10)) & (TIMELINE_BINS - 1u)), 1u);
+          if (none_left) {
+            queue_empty = true;
+            epoch++;  // whatever is still in flight deposits to the frame directly
+            continue;
+          }
+        } else {
+          // A wave's first unit is its own number in the launch (the host starts the queue head at
+          // the number of waves): thousands of waves asking one counter at the same moment would
+          // be served one at a time.  Later units come from the counter.
+          uint32_t unit = blockIdx.x * (BT >> 6) + (threadIdx.x >> 6);
+          if (epoch != 0u && lane == 0) unit = atomicAdd(ca->tile_counter, 1u);
+          // every lane is here (the loop's control is wave-uniform); read as a scalar, so that
+          // the unit's state lives in scalar registers and the loop branches on scalars
+          unit = __builtin_amdgcn_readfirstlane(unit);
+          if (ca->timeline != nullptr && lane == 0)  // profiling run: when units are fetched
+            atomicAdd(ca->timeline + (unit >= ca->q.units ? TIMELINE_BINS : 0u) +
+                          (((uint32_t)(__builtin_amdgcn_s_memrealtime() >> 10)) & (TIMELINE_BINS - 1u)), 1u);
+          if (unit >= ca->q.units) {
+            queue_empty = true;
+            epoch++;  // whatever is still in flight deposits to the frame directly
+            continue;
+          }
+          ck = fastdiv(unit, ca->q.div_tiles.m, ca->q.div_tiles.sh);
+          k = unit - ck * ca->q.tiles;
         }
+        uint32_t first, count;
+        step_samples(ck, ca->q.big, ca->q.s_big, (uint32_t)ca->chunk, (uint32_t)ca->chunk_tail,
+                     (uint32_t)ca->sample_count, first, count);
         {
-          const uint32_t ty = tile / ca->q_tiles_x;
-          tile_x0 = (tile - ty * ca->q_tiles_x) * TILE_W;
+          const uint32_t tile = (uint32_t)ca->tile_first + k * (uint32_t)ca->tile_stride;
+          const uint32_t ty = fastdiv(tile, ca->q.div_tiles_x.m, ca->q.div_tiles_x.sh);
+          tile_x0 = (tile - ty * ca->q.tiles_x) * TILE_W;
           tile_y0 = ty * TILE_H;
         }
         sample_base = (uint32_t)ca->sample_first + first;

@@ -76,3 +76,14 @@ def test_hierarchy_from_another_builder_is_checked_and_used(checker, n_sph, n_tr
     if 60 < n_sph + n_tri + n_rect < 2000:  # a chain over that many primitives is deeper than any stack
         chain = run(3)                      # (the stand-in recurses once per level: small scenes only)
         assert chain["external"] == "0" and chain["nodes"] == own["nodes"]
+
+
+def test_work_queue_hands_every_sample_out_once(checker):
+    """work_queue.h on the CPU: the division by multiplication against `/` (small, large and random
+    divisors, dividends at the multiples and the ends of the range), and for 600 launches of random
+    size, tile shard, sample count and unit sizes every (own tile, sample) numbered exactly once by
+    the one queue of the on-chip store and by the bands' queues of the HBM store."""
+    for seed in (1, 2):
+        r = subprocess.run([checker, "queue", str(seed)], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+        assert r.returncode == 0 and r.stdout.startswith("ok queue launches=600"), r.stdout + r.stderr[-3000:]
