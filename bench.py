@@ -370,8 +370,11 @@ def main(argv=None):
         traffic, traffic_note = None, None
         try:
             import hashlib
-            with open(os.path.join(ROOT, "raytracing_amd", "csrc", "kernels.hip"), "rb") as f:
-                sha16 = hashlib.sha256(f.read()).hexdigest()[:16]
+            h = hashlib.sha256()  # the device code and what it is launched with (tools/prof.sh hashes the same files)
+            for name in ("kernels.hip", "kernels.h", "work_queue.h", "scene_layout.h"):
+                with open(os.path.join(ROOT, "raytracing_amd", "csrc", name), "rb") as f:
+                    h.update(f.read())
+            sha16 = h.hexdigest()[:16]
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 tr = json.load(f).get(args.workload)
             if args.precision != "fp32":
@@ -379,7 +382,7 @@ def main(argv=None):
             elif not tr:
                 traffic_note = "no PMC profile of this workload under profiles/"
             elif tr.get("kernels_hip_sha16") != sha16:
-                traffic_note = ("profiles/traffic.json was measured on another version of kernels.hip "
+                traffic_note = ("profiles/traffic.json was measured on another version of the kernel sources "
                                 f"({tr.get('kernels_hip_sha16')} != {sha16}): run tools/prof.sh and tools/update_traffic.py")
             elif launches:
                 spp_per_launch = count * args.steps / launches

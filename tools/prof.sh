@@ -23,5 +23,5 @@ timeout -s KILL 120 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_ACTIVE_INST_V
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU SQ_INSTS_LDS_LOAD --output-format csv -d $OUT/pmc8_$TAG -- $B --steps 1 --warmup 0 --spp $SPP > $OUT/pmc8_$TAG.log 2>&1 || exit 9
 # the kernel source these counters belong to: bench.py reports roofline.traffic only while it matches
 echo $SPP > $OUT/spp_per_launch_$TAG.txt
-sha256sum $R/raytracing_amd/csrc/kernels.hip | cut -c1-16 > $OUT/kernels_hip_sha16_$TAG.txt
+cat $R/raytracing_amd/csrc/kernels.hip $R/raytracing_amd/csrc/kernels.h $R/raytracing_amd/csrc/work_queue.h $R/raytracing_amd/csrc/scene_layout.h | sha256sum | cut -c1-16 > $OUT/kernels_hip_sha16_$TAG.txt
 echo done
