@@ -51,15 +51,25 @@ def test_struct_sizes_match_the_header(tmp_path):
 
 
 def test_options_need_no_device(ht):
-    for name in ("wait_threshold", "max_blocks_per_cu", "default_batch", "chunk", "block_threads", "node_den",
-                 "wait_ratio_num", "wait_ratio_den", "force_hbm_scene", "chunk_tail", "max_waves_per_cu", "gpu_bvh",
-                 "wavefront", "wavefront_paths", "wavefront_refill"):
-        rc = ht.load().ht_set_option(name.encode(), 0 if name in ("block_threads", "force_hbm_scene", "gpu_bvh", "wavefront") else 8)
+    """Every option that include/hiptrace.h documents for ht_set_option is accepted without a
+    device, and an unknown one is refused."""
+    import re
+
+    text = open(os.path.join(ROOT, "include", "hiptrace.h")).read()
+    doc = text[text.index("Process-wide tuning knobs"):text.index("int ht_set_option")]
+    names = sorted(set(re.findall(r'"([a-z_0-9]+)"', doc)))
+    assert len(names) >= 20 and {"xcd_bands", "chunk", "wavefront", "bvh_optimise"} <= set(names), names
+    # a value every option takes; then back to the defaults the library starts with
+    defaults = {"wait_threshold": 0, "max_blocks_per_cu": 8, "max_waves_per_cu": 0, "flat_kernels": 1,
+                "bvh_optimise_max_nodes": 1 << 13, "block_threads": 0, "node_den": 2, "wait_ratio_num": 1000,
+                "wait_ratio_den": 1, "default_batch": 1024, "chunk": 0, "chunk_tail": 4, "gpu_bvh": 0,
+                "force_hbm_scene": 0, "wavefront": 0, "wavefront_paths": 1 << 24, "wavefront_refill": 32,
+                "bvh_optimise": 4, "timeline": 0, "xcd_bands": 1}
+    assert set(names) == set(defaults), set(names) ^ set(defaults)
+    for name in names:
+        rc = ht.load().ht_set_option(name.encode(), 0 if name in ("block_threads", "force_hbm_scene", "gpu_bvh", "wavefront", "timeline") else 8)
         assert rc == 0, name
-    # back to the defaults the library starts with
-    for name, v in (("wait_threshold", 40), ("max_blocks_per_cu", 8), ("default_batch", 1024), ("chunk", 0), ("chunk_tail", 4),
-                    ("block_threads", 0), ("node_den", 2), ("wait_ratio_num", 1000), ("wait_ratio_den", 1),
-                    ("max_waves_per_cu", 0), ("wavefront_paths", 1 << 24), ("wavefront_refill", 32)):
+    for name, v in defaults.items():
         ht.set_option(name, v)
     with pytest.raises(ht.HipTraceError) as e:
         ht.set_option("no_such_option", 1)
