@@ -120,6 +120,10 @@ def parse_args(argv=None):
                          "measured 103.2 instead of 94.9 ms per dragon frame on one GPU, so 1 is the default")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
                     help="a library option (ht_set_option) for this run, e.g. --set xcd_bands=0 (profiling A/B)")
+    ap.add_argument("--rehearse-collectives", action="store_true",
+                    help="with one GPU: build a one-rank RCCL process group and run the frame's gather (--shard tiles) "
+                         "or reduce (--shard samples), the barrier and the all-reduce of the timing through it, as an "
+                         "N-rank run would; the JSON line says so in 'rehearsal'")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the CPU baseline and the host-buffer leg (profiling runs)")
     ap.add_argument("--selftest-standin", action="store_true",
@@ -245,7 +249,12 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ranks_seen = 1
-    if world > 1:
+    rehearse = args.rehearse_collectives and world == 1
+    if rehearse:  # a process group of one rank, set up like a launcher would
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+    if world > 1 or rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         ranks_seen = dist.get_world_size()
@@ -270,7 +279,7 @@ def main(argv=None):
     flat = flatten(wl)
     scene = ht.Scene(flat, device=local_rank)
     precision = A.HT_PRECISION_FP64 if args.precision == "fp64" else A.HT_PRECISION_FP32
-    mode = args.shard if world > 1 else "samples"
+    mode = args.shard if (world > 1 or rehearse) else "samples"
     if mode == "tiles":
         first, count = 0, spp                      # every sample of this rank's own tiles
         t_first, t_stride = shard_tiles(rank, world)
@@ -318,18 +327,28 @@ def main(argv=None):
         def assemble():
             scene.assemble_tiles_device(W, H, world, 0, tiles_all.data_ptr(), 0, packed.data_ptr(), tstream.cuda_stream)
 
-        return FrameSlot(accum, render_shard, resolve, lambda: torch.cuda.stream(tstream), tiles=tiles,
+        slot = FrameSlot(accum, render_shard, resolve, lambda: torch.cuda.stream(tstream), tiles=tiles,
                          tiles_all=tiles_all, resolve_tiles=resolve_tiles, assemble=assemble)
+        slot.packed = packed  # the picture the frame loop leaves on rank 0
+        return slot
 
     # the frame loop and its timing are host logic shared with the CPU (gloo) test of the
     # multi-rank path: raytracing_amd/distributed.py
     in_flight = max(1, args.frames_in_flight)
     slots = [frame_slot() for _ in range(in_flight)]
-    step = make_frame_step(spp, rank, world, slots, dist, mode=mode)
+    step = make_frame_step(spp, rank, world, slots, dist, mode=mode, collectives_at_one=rehearse)
     elapsed = timed_steps(step, args.steps, args.warmup, world, dist, torch.cuda.synchronize,
-                          lambda x: torch.tensor([x], dtype=torch.float64, device=dev))
+                          lambda x: torch.tensor([x], dtype=torch.float64, device=dev), collectives_at_one=rehearse)
     accum = slots[0].accum
     stream = torch.cuda.current_stream().cuda_stream
+    rehearsal_ok = None
+    if rehearse:
+        # the picture that came through the collectives against one resolved straight from the sums
+        torch.cuda.synchronize()
+        direct = torch.empty(H * W, dtype=torch.int32, device=dev)
+        scene.resolve_device(accum.data_ptr(), W, H, spp, 0, direct.data_ptr(), stream)
+        torch.cuda.synchronize()
+        rehearsal_ok = bool(torch.equal(direct, slots[0].packed)) and bool(direct.any())
     # One more call of the same launch, alone and with statistics: the library reports the kernel
     # it chose, the samples per launch it planned and the number of launches it made.
     accum.zero_()
@@ -403,6 +422,10 @@ def main(argv=None):
             "unit": "Msamples/s",
             "n_gpus": world,
             "ranks_seen": ranks_seen,
+            "rehearsal": ("one-rank RCCL group: every frame ran its %s, the barriers and the all-reduce of the timing "
+                          "through the collective calls of an N-rank run" % ("gather of packed tiles" if mode == "tiles"
+                                                                          else "reduce of the int64 sums")) if rehearse else None,
+            "rehearsal_picture_equals_direct_resolve": rehearsal_ok,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -488,7 +511,7 @@ def main(argv=None):
             out["cpu_baseline"] = cpu_baseline(flat, cam, W, H)
         print(json.dumps(out), flush=True)
     scene.close()
-    if world > 1:
+    if world > 1 or rehearse:
         dist.barrier()
         dist.destroy_process_group()
 

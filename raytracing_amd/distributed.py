@@ -76,16 +76,19 @@ class FrameSlot:
 
 
 def make_frame_step(samples: int, rank: int, world: int, slots: List[FrameSlot], dist=None,
-                    mode: str = "samples") -> Callable[[bool], None]:
+                    mode: str = "samples", collectives_at_one: bool = False) -> Callable[[bool], None]:
     """One frame as the benchmark and a multi-process host run it: zero this rank's sum
     buffer, add the rank's sample range into it, `dist.reduce(SUM)` to rank 0, and rank 0
     resolves the picture.  Successive frames take the slots in turn: with two slots on two
     streams the drain of frame k (its last long paths, its reduce and resolve) overlaps the
-    render of frame k + 1.  `dist` is torch.distributed (None or world 1: no reduce)."""
+    render of frame k + 1.  `dist` is torch.distributed (None or world 1: no reduce, unless
+    `collectives_at_one` asks for the gather / reduce of a one-rank group as well: a rehearsal of
+    the collective calls on a machine with one GPU)."""
     if mode not in ("samples", "tiles"):
         raise ValueError("mode must be 'samples' or 'tiles'")
     first, count = shard_samples(samples, rank, world)
     frame_no = [0]
+    exchange = world > 1 or (collectives_at_one and dist is not None)
 
     def step_tiles(timed: bool) -> None:
         # every sample of this rank's own tiles (render_shard knows which they are); the rank
@@ -97,7 +100,7 @@ def make_frame_step(samples: int, rank: int, world: int, slots: List[FrameSlot],
             if samples > 0:
                 slot.render_shard(0, samples, timed)
             slot.resolve_tiles()
-            if world > 1:
+            if exchange:
                 n = slot.tiles.numel()
                 parts = [slot.tiles_all[g * n:(g + 1) * n] for g in range(world)] if rank == 0 else None
                 dist.gather(slot.tiles, gather_list=parts, dst=0)
@@ -114,7 +117,7 @@ def make_frame_step(samples: int, rank: int, world: int, slots: List[FrameSlot],
             slot.accum.zero_()
             if count > 0:
                 slot.render_shard(first, count, timed)
-            if world > 1:
+            if exchange:
                 dist.reduce(slot.accum, dst=0, op=dist.ReduceOp.SUM)
             if rank == 0:
                 slot.resolve()
@@ -123,16 +126,19 @@ def make_frame_step(samples: int, rank: int, world: int, slots: List[FrameSlot],
 
 
 def timed_steps(step: Callable[[bool], None], steps: int, warmup: int, world: int, dist=None,
-                device_sync: Callable[[], None] = lambda: None, max_tensor: Callable[[float], "object"] = None) -> float:
+                device_sync: Callable[[], None] = lambda: None, max_tensor: Callable[[float], "object"] = None,
+                collectives_at_one: bool = False) -> float:
     """`warmup` untimed steps, then exactly `steps` timed ones bracketed by device sync +
     barrier + device sync on both sides; returns the elapsed seconds of the slowest rank
     (all_reduce MAX), the same number on every rank.  `max_tensor(x)` makes the one-element
     float64 tensor the backend can reduce (a device tensor for RCCL)."""
     import time
 
+    exchange = world > 1 or (collectives_at_one and dist is not None)
+
     def fence():
         device_sync()
-        if world > 1:
+        if exchange:
             dist.barrier()
         device_sync()
 
@@ -144,7 +150,7 @@ def timed_steps(step: Callable[[bool], None], steps: int, warmup: int, world: in
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if exchange:
         t = max_tensor(elapsed)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
