@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <mutex>
@@ -35,6 +36,9 @@ struct LaunchShape {
 // Work-queue heads: every launch takes the next one of a ring, so launches of one scene
 // handle may overlap on different streams (up to QUEUE_SLOTS of them in flight).
 constexpr uint32_t QUEUE_SLOTS = 64, QUEUE_SLOT_BYTES = 256;
+
+// buffers of a handle's share of a sharded render (ht_scene::d_shard)
+enum { SHARD_ACCUM = 0, SHARD_STAGING, SHARD_MEAN_TILES, SHARD_PACKED_TILES, SHARD_GATHERED, SHARD_BUFFERS };
 
 struct ht_scene {
   HostScene hs;
@@ -67,6 +71,11 @@ struct ht_scene {
   // option "timeline" is on (ht_debug_timeline reads and clears them)
   std::mutex timeline_mutex;
   uint32_t* d_timeline = nullptr;
+  // Device buffers of ht_render_sharded (this handle's sums, staging and tile buffers), kept
+  // between calls and grown on demand; a sharded render holds shard_mutex of every handle it uses
+  std::mutex shard_mutex;
+  void* d_shard[SHARD_BUFFERS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t shard_bytes[SHARD_BUFFERS] = {0, 0, 0, 0, 0};
   // HIP events of finished calls, reused by later ones
   std::mutex event_mutex;
   std::vector<hipEvent_t> timing_events, plain_events;
@@ -245,6 +254,37 @@ hipError_t grow(T*& buf, size_t& have, size_t pixels, size_t elem) {
   if (e == hipSuccess) have = pixels;
   return e;
 }
+
+// One of a handle's sharded-render buffers, at least `bytes` large (the handle's device is current,
+// its shard_mutex held).
+hipError_t shard_buffer(ht_scene* s, int which, size_t bytes, void** out) {
+  *out = nullptr;
+  if (bytes == 0) return hipSuccess;
+  if (s->shard_bytes[which] < bytes) {
+    if (s->d_shard[which]) (void)hipFree(s->d_shard[which]);
+    s->d_shard[which] = nullptr;
+    s->shard_bytes[which] = 0;
+    const hipError_t e = hipMalloc(&s->d_shard[which], bytes);
+    if (e != hipSuccess) return e;
+    s->shard_bytes[which] = bytes;
+  }
+  *out = s->d_shard[which];
+  return hipSuccess;
+}
+
+// Locks the shard workspaces of all handles of a sharded render, in address order (two renders over
+// the same handles in different orders cannot deadlock).
+struct ShardLocks {
+  std::vector<ht_scene*> held;
+  ShardLocks(ht_scene* const* scenes, int n) {
+    held.assign(scenes, scenes + n);
+    std::sort(held.begin(), held.end());
+    for (ht_scene* s : held) s->shard_mutex.lock();
+  }
+  ~ShardLocks() {
+    for (auto it = held.rbegin(); it != held.rend(); ++it) (*it)->shard_mutex.unlock();
+  }
+};
 
 // Workgroup size and count of the render kernel for this scene: the combination that keeps
 // the most waves resident per CU; smaller groups win ties (measured on the Cornell box, 32
@@ -681,6 +721,8 @@ void ht_scene_destroy(ht_scene* s) {
     if (s->d_counters) (void)hipFree(s->d_counters);
     if (s->d_wf) (void)hipFree(s->d_wf);
     if (s->d_timeline) (void)hipFree(s->d_timeline);
+    for (int k = 0; k < SHARD_BUFFERS; ++k)
+      if (s->d_shard[k]) (void)hipFree(s->d_shard[k]);
     if (s->d_host_accum) (void)hipFree(s->d_host_accum);
     if (s->d_host_mean) (void)hipFree(s->d_host_mean);
     if (s->d_host_packed) (void)hipFree(s->d_host_packed);
@@ -1009,25 +1051,20 @@ static int render_sharded_tiles(ht_scene* const* scenes, int32_t n, const ht_cam
     std::string error;
   };
   std::vector<Shard> shards((size_t)n);
+  // The buffers live in the handles' shard workspaces (allocated by the first call of a size, kept).
+  ShardLocks locks(scenes, n);
+  auto release = []() {};
   float* d_mean_all = nullptr;       // on the first device: every shard's tile buffers, shard g at g * shard_px
   uint32_t* d_packed_all = nullptr;
-  auto release = [&]() {
-    for (int k = 0; k < n; ++k) {
-      DeviceGuard g(scenes[k]->device);
-      Shard& sh = shards[(size_t)k];
-      if (sh.d_accum) (void)hipFree(sh.d_accum);
-      if (k > 0 && sh.d_mean_tiles) (void)hipFree(sh.d_mean_tiles);
-      if (k > 0 && sh.d_packed_tiles) (void)hipFree(sh.d_packed_tiles);
-    }
-    DeviceGuard g(scenes[0]->device);
-    if (d_mean_all) (void)hipFree(d_mean_all);
-    if (d_packed_all) (void)hipFree(d_packed_all);
-  };
   {
     DeviceGuard g(scenes[0]->device);
     hipError_t e = g.ok ? hipSuccess : hipErrorInvalidDevice;
-    if (e == hipSuccess && rgb_linear) e = hipMalloc((void**)&d_mean_all, shard_px * (size_t)n * 3 * sizeof(float));
-    if (e == hipSuccess && rgb_packed) e = hipMalloc((void**)&d_packed_all, shard_px * (size_t)n * sizeof(uint32_t));
+    const size_t mean_bytes = rgb_linear ? shard_px * (size_t)n * 3 * sizeof(float) : 0;
+    const size_t packed_bytes = rgb_packed ? shard_px * (size_t)n * sizeof(uint32_t) : 0;
+    void* all = nullptr;  // means first (a multiple of 256 bytes: shard_px is a multiple of 64), then the packed codes
+    if (e == hipSuccess) e = shard_buffer(scenes[0], SHARD_GATHERED, mean_bytes + packed_bytes, &all);
+    if (e == hipSuccess && rgb_linear) d_mean_all = (float*)all;
+    if (e == hipSuccess && rgb_packed) d_packed_all = (uint32_t*)((uint8_t*)all + mean_bytes);
     if (e != hipSuccess) {
       (void)hipGetLastError();
       release();
@@ -1042,14 +1079,16 @@ static int render_sharded_tiles(ht_scene* const* scenes, int32_t n, const ht_cam
     sh.params.device = -1;
     memset(&sh.stats, 0, sizeof sh.stats);
     DeviceGuard g(scenes[k]->device);
-    hipError_t e = g.ok ? hipMalloc((void**)&sh.d_accum, pixels * 3 * sizeof(int64_t)) : hipErrorInvalidDevice;
+    hipError_t e = g.ok ? shard_buffer(scenes[k], SHARD_ACCUM, pixels * 3 * sizeof(int64_t), (void**)&sh.d_accum) : hipErrorInvalidDevice;
     if (e == hipSuccess) e = hipMemset(sh.d_accum, 0, pixels * 3 * sizeof(int64_t));
     if (k == 0) {  // the first shard resolves straight into its place in the gathered arrays
       sh.d_mean_tiles = d_mean_all;
       sh.d_packed_tiles = d_packed_all;
     } else {
-      if (e == hipSuccess && rgb_linear) e = hipMalloc((void**)&sh.d_mean_tiles, shard_px * 3 * sizeof(float));
-      if (e == hipSuccess && rgb_packed) e = hipMalloc((void**)&sh.d_packed_tiles, shard_px * sizeof(uint32_t));
+      if (e == hipSuccess && rgb_linear)
+        e = shard_buffer(scenes[k], SHARD_MEAN_TILES, shard_px * 3 * sizeof(float), (void**)&sh.d_mean_tiles);
+      if (e == hipSuccess && rgb_packed)
+        e = shard_buffer(scenes[k], SHARD_PACKED_TILES, shard_px * sizeof(uint32_t), (void**)&sh.d_packed_tiles);
     }
     if (e != hipSuccess) {
       (void)hipGetLastError();
@@ -1187,13 +1226,9 @@ int ht_render_sharded(ht_scene* const* scenes, int32_t n, const ht_camera* cam, 
     std::string error;
   };
   std::vector<Shard> shards((size_t)n);
-  auto release = [&]() {
-    for (int k = 0; k < n; ++k) {
-      DeviceGuard g(scenes[k]->device);
-      if (shards[(size_t)k].d_accum) (void)hipFree(shards[(size_t)k].d_accum);
-      if (shards[(size_t)k].d_staging) (void)hipFree(shards[(size_t)k].d_staging);
-    }
-  };
+  // The buffers live in the handles' shard workspaces (allocated by the first call of a size, kept).
+  ShardLocks locks(scenes, n);
+  auto release = []() {};
   // Slice k of the frame is summed on shard k's device (words [lo_k, hi_k), 16-byte aligned):
   // every device pulls its slice from every other one at the same time, each pair over its
   // own xGMI link, and adds what arrived; then the summed slices go to the first device.
@@ -1212,10 +1247,10 @@ int ht_render_sharded(ht_scene* const* scenes, int32_t n, const ht_camera* cam, 
     memset(&sh.stats, 0, sizeof sh.stats);
     DeviceGuard g(scenes[k]->device);
     const size_t slice = lo[(size_t)k + 1] - lo[(size_t)k];
-    hipError_t e = g.ok ? hipMalloc((void**)&sh.d_accum, bytes) : hipErrorInvalidDevice;
+    hipError_t e = g.ok ? shard_buffer(scenes[k], SHARD_ACCUM, bytes, (void**)&sh.d_accum) : hipErrorInvalidDevice;
     if (e == hipSuccess) e = hipMemset(sh.d_accum, 0, bytes);
     if (e == hipSuccess && n > 1 && slice > 0)
-      e = hipMalloc((void**)&sh.d_staging, slice * (size_t)(n - 1) * sizeof(int64_t));
+      e = shard_buffer(scenes[k], SHARD_STAGING, slice * (size_t)(n - 1) * sizeof(int64_t), (void**)&sh.d_staging);
     if (e != hipSuccess) {
       (void)hipGetLastError();
       release();

@@ -84,3 +84,13 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def free_device_bytes() -> int:
+    """Free device memory as hipMemGetInfo reports it (after a device synchronisation)."""
+    h = hip()
+    h.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    assert h.hipDeviceSynchronize() == 0
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    assert h.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return int(free.value)

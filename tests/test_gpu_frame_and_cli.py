@@ -131,6 +131,34 @@ def test_sharded_render_equals_one_render(dev, flat_scene, n):
             s.close()
 
 
+@pytest.mark.parametrize("mode", ["samples", "tiles"])
+def test_sharded_render_keeps_its_buffers(dev, flat_scene, mode):
+    """The shards' sums, staging and tile buffers live in the scene handles: a second
+    ht_render_sharded of the same size allocates no device memory, a smaller one neither, and
+    the pictures stay ht_render's."""
+    from hipmem import free_device_bytes
+    from raytracing_amd import _abi as A
+
+    cam, _, flat = flat_scene("dragon")
+    W, H = 160, 96
+    shard_mode = A.HT_SHARD_TILES if mode == "tiles" else A.HT_SHARD_SAMPLES
+    scenes = [dev.Scene(flat, device=0) for _ in range(3)]
+    try:
+        whole = scenes[0].render(cam, W, H, 6, seed=8)
+        first = dev.render_sharded(scenes, cam, W, H, 6, seed=8, shard_mode=shard_mode)
+        np.testing.assert_array_equal(first["packed"], whole["packed"])
+        before = free_device_bytes()
+        again = dev.render_sharded(scenes, cam, W, H, 6, seed=8, shard_mode=shard_mode)
+        small = dev.render_sharded(scenes, cam, W // 2, H // 2, 6, seed=8, shard_mode=shard_mode)
+        assert free_device_bytes() == before
+        np.testing.assert_array_equal(again["packed"], whole["packed"])
+        np.testing.assert_array_equal(again["rgb"], whole["rgb"])
+        np.testing.assert_array_equal(small["packed"], scenes[0].render(cam, W // 2, H // 2, 6, seed=8)["packed"])
+    finally:
+        for s in scenes:
+            s.close()
+
+
 def test_sharded_render_errors(dev, flat_scene):
     cam, _, flat = flat_scene("scene")
     _, _, other = flat_scene("dragon")
