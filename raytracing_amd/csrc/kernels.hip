@@ -572,6 +572,13 @@ __device__ __forceinline__ void rect_test_axis(const Scene& sc, const Ray<R>& ra
   const R da = K == 0 ? ray.d.y : ray.d.x, db = K == 2 ? ray.d.y : ray.d.z;
   const R ik = K == 2 ? ray.inv.z : (K == 1 ? ray.inv.y : ray.inv.x);  // 1 / d_k
   R t = (g.k - ok_) * ik;
+  if constexpr (sizeof(R) == 8) {
+    // the validation path divides, as the reference does (Hittable.scala:56): a ray through the
+    // line where two walls meet lies on the inclusive edge of both rects only in that arithmetic;
+    // a product with 1/d_k puts it an ulp outside of both, and the ray leaves the box there
+    const R dk = K == 2 ? ray.d.z : (K == 1 ? ray.d.y : ray.d.x);
+    t = (g.k - ok_) / dk;
+  }
   R a = oa + t * da, bb = ob + t * db;
   const bool ok = t >= t_min && t < tv.best_t && a >= g.a0 && a <= g.a1 && bb >= g.b0 && bb <= g.b1;
   tv.best_t = ok ? t : tv.best_t;

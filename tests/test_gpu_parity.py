@@ -59,15 +59,37 @@ def psnr_codes(a, b):
     return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
 
 
-@pytest.mark.parametrize("name", SCENES)
-def test_first_hit_fp64_matches_oracle(dev, oracle_mod, flat_scene, name):
+# the frames of BASELINE.json's configurations, at their full sizes
+FULL_SIZE = [("dragon", 1920, 1080), ("random", 1920, 1080), ("cornell", 1024, 1024), ("perlin", 1920, 1080),
+             ("checker", 1920, 1080), ("scene", 400, 225)]
+
+
+@pytest.mark.parametrize("name,W,H", [(n, 160, 90) for n in SCENES] + FULL_SIZE)
+def test_first_hit_fp64_matches_oracle(dev, oracle_mod, flat_scene, name, W, H):
     cam, flat, s = gpu_scene(dev, flat_scene, name)
-    W, H = 160, 90
     o = oracle_mod.OracleScene(flat, bvh_seed=1).first_hit(cam, W, H)
     g = s.first_hit(cam, W, H, precision=A.HT_PRECISION_FP64)
-    assert np.array_equal(g["prim_id"], o["prim_id"])
     hit = o["prim_id"] >= 0
-    assert np.all(np.isinf(g["t64"][~hit]))
+    # Same primitive everywhere, except on rays that graze an edge: a ray through the line where
+    # two walls of the Cornell box meet lies on the inclusive edge of both rects (Hittable.scala:57-62),
+    # which of the two the reference reports depends on its randomly built tree (BVH.scala:12-13, 19;
+    # the oracle's answer changes with its tree seed there), and an arithmetic that rounds
+    # differently from the JVM's (the device fuses multiply-adds) may find the point an ulp outside
+    # of both.  Such a pixel is told by the oracle itself: its answer changes when the ray moves by
+    # an ulp of its direction.
+    differ = g["prim_id"] != o["prim_id"]
+    if differ.any():
+        osc = oracle_mod.OracleScene(flat, bvh_seed=1)
+        d = 4e-16 * W
+        unstable = np.zeros((H, W), bool)
+        for dx, dy in ((d, 0), (-d, 0), (0, d), (0, -d), (d, d), (-d, -d), (d, -d), (-d, d)):
+            unstable |= osc.first_hit(cam, W, H, off=(0.5 + dx, 0.5 + dy))["prim_id"] != o["prim_id"]
+        unstable |= oracle_mod.OracleScene(flat, bvh_seed=2).first_hit(cam, W, H)["prim_id"] != o["prim_id"]
+        assert not np.any(differ & ~unstable), "primitive id differs on a pixel whose oracle answer is stable"
+        assert differ.mean() < 5e-4
+        print(f"{name} {W}x{H}: {int(differ.sum())} pixels on rays that graze an edge (oracle unstable on {int(unstable.sum())})")
+        hit = hit & ~differ
+    assert np.all(np.isinf(g["t64"][(o["prim_id"] < 0) & ~differ]))
     np.testing.assert_allclose(g["t64"][hit], o["t"][hit], rtol=1e-9)
     # the oracle's own (ray.at(t) - center)/radius carries ~1e-10 of cancellation on small
     # far spheres, so normals are compared as vectors
@@ -75,10 +97,9 @@ def test_first_hit_fp64_matches_oracle(dev, oracle_mod, flat_scene, name):
     assert nerr.size == 0 or nerr.max() < 1e-8
 
 
-@pytest.mark.parametrize("name", SCENES)
-def test_first_hit_fp32_matches_oracle(dev, oracle_mod, flat_scene, name):
+@pytest.mark.parametrize("name,W,H", [(n, 320, 180) for n in SCENES] + FULL_SIZE)
+def test_first_hit_fp32_matches_oracle(dev, oracle_mod, flat_scene, name, W, H):
     cam, flat, s = gpu_scene(dev, flat_scene, name)
-    W, H = 320, 180
     osc = oracle_mod.OracleScene(flat, bvh_seed=1)
     o = osc.first_hit(cam, W, H)
     d = 2.5e-7 * W  # about one ulp of an fp32 ray direction, in pixels
@@ -105,7 +126,7 @@ def test_first_hit_fp32_matches_oracle(dev, oracle_mod, flat_scene, name):
     assert np.all(nerr <= 1e-5 + 8 * sens_n[ok]), f"normal error {nerr.max():.3e}"
     if ok.any():
         t_in, n_in = float((terr <= 1e-5).mean()), float((nerr <= 1e-5).mean())
-        print(f"{name}: inside the plain 1e-5: t {t_in:.5f} (max {terr.max():.2e}), "
+        print(f"{name} {W}x{H}: inside the plain 1e-5: t {t_in:.5f} (max {terr.max():.2e}), "
               f"normal {n_in:.5f} (max {nerr.max():.2e}, p99.9 {np.percentile(nerr, 99.9):.2e}); "
               f"ids differ on {int(mism.sum())} unstable pixels")
         assert t_in >= 0.999, f"{name}: {1 - t_in:.2e} of the hit pixels have t outside 1e-5"
