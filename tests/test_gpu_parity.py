@@ -237,7 +237,11 @@ def _psnr(a, b):
 
 
 @pytest.mark.parametrize("name,W,H,spp,bin_", [("dragon", 160, 90, 320, 1), ("random", 160, 90, 640, 1),
-                                                ("cornell", 128, 128, 1024, 8)])
+                                                ("cornell", 128, 128, 1024, 8),
+                                                # a ninth of the headline frames (the oracle follows ten million
+                                                # paths a second on sixteen cores: about a minute for these three)
+                                                ("dragon", 640, 360, 320, 1), ("random", 640, 360, 640, 1),
+                                                ("cornell", 512, 512, 1024, 8)])
 def test_converged_image_psnr_vs_reference_sampler(dev, oracle_mod, flat_scene, name, W, H, spp, bin_):
     """The converged-image gate on the headline scenes: device (fp32, Philox, direct
     sampling) against the oracle running the reference's own rejection samplers
