@@ -20,6 +20,7 @@ def dev(ht):
     ht.set_option("force_hbm_scene", 0)
     ht.set_option("xcd_bands", 1)
     ht.set_option("timeline", 0)
+    ht.set_option("chunk", 0)
 
 
 def sums(dev, s, cam, W, H, spp, **kw):
@@ -57,10 +58,12 @@ def test_every_unit_is_fetched_once(dev, flat_scene):
     W, H, spp = 320, 180, 24
     with dev.Scene(flat, device=0) as s:
         n = {}
+        dev.set_option("chunk", 8)  # (left to itself a launch this small takes smaller units)
         for bands in (0, 1):
             dev.set_option("xcd_bands", bands)
             dev.set_option("timeline", 1)
             sums(dev, s, cam, W, H, spp)
             n[bands] = int(s.debug_timeline()[0].sum())
             dev.set_option("timeline", 0)
+        dev.set_option("chunk", 0)
         assert n[0] == n[1] == 40 * 23 * (2 + 2)  # 16 samples in units of 8, the last 8 in units of 4
