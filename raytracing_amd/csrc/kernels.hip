@@ -480,19 +480,26 @@ template <typename R>
 struct TriGeom {
   V3<R> A, e1, e2, n;  // fp32: e1, e2 hold U, V
 };
-template <typename R, bool WIDE = false>
+// WHOLE: how much of the record is read in whole 16-byte words before any of it is used (fp32)
+enum { TRI_AS_NEEDED = 0, TRI_FIRST_AND_LAST = 1, TRI_ALL = 2 };
+template <typename R, int WHOLE = TRI_AS_NEEDED>
 __device__ __forceinline__ TriGeom<R> load_tri(const Scene& sc, uint32_t idx) {
   typename M<R>::R4 q0 = load_r4<R>(sc, sc.L.tri, idx * 3u);
   typename M<R>::R4 q1 = load_r4<R>(sc, sc.L.tri, idx * 3u + 1u);
   typename M<R>::R4 q2 = load_r4<R>(sc, sc.L.tri, idx * 3u + 2u);
-  if constexpr (sizeof(R) == 4 && WIDE) {
+  if constexpr (sizeof(R) == 4 && WHOLE == TRI_ALL) {
     // HBM store: the record is read as the three aligned 16-byte words it is made of, all issued
     // before the first is used.  Left to itself the compiler reads a triangle in two rounds of two
     // narrower loads each (A and n, then the rest once t is known): four accesses of the vector
-    // cache per lane where three do, and two waits where one does.  (On chip the reads are LDS
-    // reads, and the kernel held to 64 vector registers has none to spare for the twelve values.)
+    // cache per lane where three do, and two waits where one does.
     asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
                       "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w));
+  } else if constexpr (sizeof(R) == 4 && WHOLE == TRI_FIRST_AND_LAST) {
+    // On chip, in the kernels of triangle hierarchies (LDS reads; the kernel held to 64 vector registers
+    // has no room for all twelve values at once): the first and the last word whole (A and n, what t
+    // needs), the middle one after them; the compiler then reads that one whole as well.  Three
+    // ds_read_b128 and one wait per triangle instead of six narrower reads and two waits.
+    asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w));
   }
   TriGeom<R> g;
   g.A = mk<R>(q0.x, q0.y, q0.z);
@@ -538,11 +545,11 @@ __device__ __forceinline__ void sphere_test(const Scene& sc, const Ray<R>& ray, 
     tv.best_ref = ok ? ref : tv.best_ref;
   }
 }
-template <typename R, bool CNT, bool WIDE = false>
+template <typename R, bool CNT, int WHOLE = TRI_AS_NEEDED>
 __device__ __forceinline__ void triangle_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t ref,
                                               uint32_t idx, R t_min, Cnt& cnt) {
   if (CNT) cnt.v[CTR_TRI]++;
-  TriGeom<R> g = load_tri<R, WIDE>(sc, idx);
+  TriGeom<R> g = load_tri<R, WHOLE>(sc, idx);
   R det, t, u, v;
   tri_solve<R>(g, ray, det, t, u, v);
   R w = (R)1 - u - v;
@@ -552,12 +559,12 @@ __device__ __forceinline__ void triangle_test(const Scene& sc, const Ray<R>& ray
 }
 // A triangle leaf: triangle idx, and for a pair (KIND_TRI_PAIR) triangle idx + 1 as well.  The
 // hit is recorded under the single triangle's own reference.  Sphere leaves likewise.
-template <typename R, bool CNT, bool WIDE>
+template <typename R, bool CNT, bool WIDE, int WHOLE = (WIDE ? TRI_ALL : TRI_AS_NEEDED)>
 __device__ __forceinline__ void triangle_pair_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t idx,
                                                    bool pair, R t_min, Cnt& cnt) {
   const uint32_t single = RefT<WIDE>::LEAF | (KIND_TRIANGLE << RefT<WIDE>::KIND_SHIFT);
-  triangle_test<R, CNT, WIDE>(sc, ray, tv, single | idx, idx, t_min, cnt);
-  if (pair) triangle_test<R, CNT, WIDE>(sc, ray, tv, single | (idx + 1u), idx + 1u, t_min, cnt);
+  triangle_test<R, CNT, WHOLE>(sc, ray, tv, single | idx, idx, t_min, cnt);
+  if (pair) triangle_test<R, CNT, WHOLE>(sc, ray, tv, single | (idx + 1u), idx + 1u, t_min, cnt);
 }
 template <typename R, bool CNT, bool WIDE>
 __device__ __forceinline__ void sphere_pair_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t idx,
@@ -604,7 +611,7 @@ template <typename R, bool CNT, bool WIDE>
 __device__ __forceinline__ void prim_test(const Scene& sc, const Ray<R>& ray, Trav<R>& tv, uint32_t ref,
                                           R t_min, Cnt& cnt) {
   const uint32_t kind = (ref >> RefT<WIDE>::KIND_SHIFT) & 7u, idx = ref & RefT<WIDE>::INDEX_MASK;
-  if (kind == KIND_TRIANGLE) triangle_test<R, CNT, WIDE>(sc, ray, tv, ref, idx, t_min, cnt);
+  if (kind == KIND_TRIANGLE) triangle_test<R, CNT, (WIDE ? TRI_ALL : TRI_AS_NEEDED)>(sc, ray, tv, ref, idx, t_min, cnt);
   else if (kind == KIND_TRI_PAIR) triangle_pair_test<R, CNT, WIDE>(sc, ray, tv, idx, true, t_min, cnt);
   else if (kind == KIND_SPH_PAIR) sphere_pair_test<R, CNT, WIDE>(sc, ray, tv, idx, true, t_min, cnt);
   else if (kind == KIND_SPHERE || kind == KIND_BIG_SPHERE) sphere_test<R, CNT>(sc, ray, tv, ref, kind, idx, t_min, cnt);
@@ -618,7 +625,8 @@ __device__ __forceinline__ void leaf_test(const Scene& sc, const Ray<R>& ray, Tr
                                           R t_min, Cnt& cnt) {
   const uint32_t idx = ref & RefT<WIDE>::INDEX_MASK;
   if (TRIS || sc.L.tree_kinds == TREE_TRIANGLES)
-    triangle_pair_test<R, CNT, WIDE>(sc, ray, tv, idx, ((ref >> RefT<WIDE>::KIND_SHIFT) & 7u) == KIND_TRI_PAIR, t_min, cnt);
+    triangle_pair_test<R, CNT, WIDE, (WIDE ? TRI_ALL : (TRIS ? TRI_FIRST_AND_LAST : TRI_AS_NEEDED))>(
+        sc, ray, tv, idx, ((ref >> RefT<WIDE>::KIND_SHIFT) & 7u) == KIND_TRI_PAIR, t_min, cnt);
   else if (sc.L.tree_kinds == TREE_SPHERES)
     sphere_pair_test<R, CNT, WIDE>(sc, ray, tv, idx, ((ref >> RefT<WIDE>::KIND_SHIFT) & 7u) == KIND_SPH_PAIR, t_min, cnt);
   else prim_test<R, CNT, WIDE>(sc, ray, tv, ref, t_min, cnt);
