@@ -492,14 +492,14 @@ __device__ __forceinline__ TriGeom<R> load_tri(const Scene& sc, uint32_t idx) {
     // before the first is used.  Left to itself the compiler reads a triangle in two rounds of two
     // narrower loads each (A and n, then the rest once t is known): four accesses of the vector
     // cache per lane where three do, and two waits where one does.
-    asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w),
-                      "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w));
+    asm volatile("" ::"v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q1.x), "v"(q1.y), "v"(q1.z), "v"(q1.w),
+                 "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w));
   } else if constexpr (sizeof(R) == 4 && WHOLE == TRI_FIRST_AND_LAST) {
     // On chip, in the kernels of triangle hierarchies (LDS reads; the kernel held to 64 vector registers
     // has no room for all twelve values at once): the first and the last word whole (A and n, what t
     // needs), the middle one after them; the compiler then reads that one whole as well.  Three
     // ds_read_b128 and one wait per triangle instead of six narrower reads and two waits.
-    asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w));
+    asm volatile("" ::"v"(q0.x), "v"(q0.y), "v"(q0.z), "v"(q0.w), "v"(q2.x), "v"(q2.y), "v"(q2.z), "v"(q2.w));
   }
   TriGeom<R> g;
   g.A = mk<R>(q0.x, q0.y, q0.z);
