@@ -386,8 +386,6 @@ int ht_scene_get_info(const ht_scene* scene, ht_scene_info* out);
  *   "bvh_optimise_max_nodes"  largest hierarchy (inner nodes) the optimiser is run over (8192)
  *   "block_threads"     force the workgroup size (multiple of 128; 0 = choose for occupancy)
  *   "node_den"          node steps continue while inner-node lanes * node_den >= travelling lanes
- *   "wait_ratio_num" / "wait_ratio_den"  traversal also yields to shading when
- *                       waiting lanes / travelling lanes >= num / den
  *   "default_batch"     samples per launch when ht_render_params.batch = 0
  *   "chunk"             samples of one 8x8 tile that form one unit of the work queue
  *                       (0, the default: 16 for launches of 1024 samples or more, else 8)

@@ -132,7 +132,7 @@ std::atomic<int> g_wait_threshold{0};  // 0: by store (40 on chip, 32 in HBM, wh
 std::atomic<int> g_max_blocks_per_cu{8};
 std::atomic<int> g_max_waves_per_cu{0};  // 0: what the kernel variant admits
 std::atomic<int> g_block_threads{0};  // 0: choose
-std::atomic<int> g_node_den{2}, g_wait_num{1000}, g_wait_den{1};
+std::atomic<int> g_node_den{2};
 std::atomic<int> g_default_batch{1024};
 std::atomic<int> g_chunk{0};  // 0: by launch size
 std::atomic<int> g_chunk_tail{4};
@@ -405,8 +405,7 @@ int make_plan(ht_scene* s, const ht_camera* cam, const ht_render_params* p, int6
   a.wait_threshold = g_wait_threshold.load();
   if (a.wait_threshold <= 0) a.wait_threshold = a.L.wide ? 32 : 40;
   a.node_den = g_node_den.load();
-  a.wait_ratio_num = g_wait_num.load();
-  a.wait_ratio_den = g_wait_den.load();
+  a.reserved1 = a.reserved2 = 0;
   a.inv_w1 = 1.0f / (float)(p->width - 1);
   a.inv_h1 = 1.0f / (float)(p->height - 1);
   a.tile_stride = std::max(1, p->tile_stride);
@@ -696,8 +695,6 @@ int ht_set_option(const char* name, int value) {
   if (!strcmp(name, "xcd_bands")) { g_xcd_bands = value != 0; return HT_OK; }
   if (!strcmp(name, "block_threads")) { g_block_threads = value; g_shape_generation++; return HT_OK; }
   if (!strcmp(name, "node_den")) { g_node_den = std::max(1, value); return HT_OK; }
-  if (!strcmp(name, "wait_ratio_num")) { g_wait_num = std::max(1, value); return HT_OK; }
-  if (!strcmp(name, "wait_ratio_den")) { g_wait_den = std::max(1, value); return HT_OK; }
   if (!strcmp(name, "flat_kernels")) { g_flat_kernels = value ? 1 : 0; g_shape_generation++; return HT_OK; }
   if (!strcmp(name, "bvh_optimise_max_nodes")) { g_bvh_optimise_max_nodes = std::max(0, value); return HT_OK; }
   if (!strcmp(name, "bvh_optimise")) { g_bvh_optimise = std::min(64, std::max(0, value)); return HT_OK; }

@@ -39,7 +39,7 @@ struct RenderArgs {
   uint32_t philox_keys[20];  // round keys of Philox4x32-10 for that seed: (lo + r*0x9E3779B9, hi + r*0xBB67AE85)
   int32_t wait_threshold;  // lanes that may wait for shading before traversal yields
   int32_t node_den;        // node steps go on while inner lanes * node_den >= travelling lanes
-  int32_t wait_ratio_num, wait_ratio_den;  // traversal also yields when waiting/travelling >= num/den
+  int32_t reserved1, reserved2;
   float inv_w1, inv_h1;    // 1/(W-1), 1/(H-1) correctly rounded (jittered fp32 sample positions)
   int32_t tile_first;      // this launch renders the 8x8 tiles tile_first, tile_first + tile_stride, ... of the
   int32_t tile_stride;     //   frame (row-major tile numbers); 0 / 1: every tile

@@ -360,13 +360,22 @@ __device__ __forceinline__ void slab2(const Ray<R>& r, const R b[12], R t_min, R
     const float cx0 = __builtin_fmaf(b[0], r.inv.x, -r.oi.x), cx1 = __builtin_fmaf(b[1], r.inv.x, -r.oi.x), ex0 = b[2] * aix, ex1 = b[3] * aix;
     const float cy0 = __builtin_fmaf(b[4], r.inv.y, -r.oi.y), cy1 = __builtin_fmaf(b[5], r.inv.y, -r.oi.y), ey0 = b[6] * aiy, ey1 = b[7] * aiy;
     const float cz0 = __builtin_fmaf(b[8], r.inv.z, -r.oi.z), cz1 = __builtin_fmaf(b[9], r.inv.z, -r.oi.z), ez0 = b[10] * aiz, ez1 = b[11] * aiz;
-    tn0 = __builtin_fmaxf(__builtin_fmaxf(cx0 - ex0, cy0 - ey0), __builtin_fmaxf(cz0 - ez0, t_min));
-    tn1 = __builtin_fmaxf(__builtin_fmaxf(cx1 - ex1, cy1 - ey1), __builtin_fmaxf(cz1 - ez1, t_min));
+    // The entry distances are ordered as the signed integers of their bit patterns, which puts
+    // every negative number below every positive one and the negative ones in reverse.  An entry
+    // that is not ahead of the ray then needs no clamp to t_min: a box around the origin has a
+    // negative entry and a positive exit and is taken, and a box behind the ray has a negative
+    // exit on some axis k, where entry_k <= exit_k < 0 makes bits(entry_k) >= bits(exit_k), so the
+    // largest entry pattern is not below the exit's and the box is left out (but for a box of no
+    // thickness, which costs a visit and no hit: primitives test t >= t_min themselves).
+    const int n0 = max(max(__float_as_int(cx0 - ex0), __float_as_int(cy0 - ey0)), __float_as_int(cz0 - ez0));
+    const int n1 = max(max(__float_as_int(cx1 - ex1), __float_as_int(cy1 - ey1)), __float_as_int(cz1 - ez1));
     const float tf0 = __builtin_fminf(__builtin_fminf(cx0 + ex0, cy0 + ey0), cz0 + ez0);
     const float tf1 = __builtin_fminf(__builtin_fminf(cx1 + ex1, cy1 + ey1), cz1 + ez1);
     const float w = M<float>::slab_widen();
-    h0 = tn0 <= __builtin_fminf(tf0 * w, t_far);
-    h1 = tn1 <= __builtin_fminf(tf1 * w, t_far);
+    h0 = n0 <= __float_as_int(__builtin_fminf(tf0 * w, t_far));
+    h1 = n1 <= __float_as_int(__builtin_fminf(tf1 * w, t_far));
+    tn0 = __int_as_float(n0);  // the caller orders the two children by these: as numbers where both
+    tn1 = __int_as_float(n1);  // are ahead, in no particular order where the ray starts inside both
   } else {
     h0 = slab<R>(r, b[0], b[4], b[8], b[2], b[6], b[10], t_min, t_far, tn0);
     h1 = slab<R>(r, b[1], b[5], b[9], b[3], b[7], b[11], t_min, t_far, tn1);
@@ -1418,13 +1427,22 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
     //         step for the lanes that reached a primitive; until enough rays are done ----
     if constexpr (FLAT) continue;
     const int n_live = __popcll(__ballot(state == ST_LIVE));
-    while (__ballot(tv.cur != RF::EMPTY) != 0ull) {
+    // The traversal yields to the next round once `wait_threshold` of the live lanes have finished
+    // their rays, i.e. when the travelling lanes are down to `stop` (or to none).  The loop is
+    // written for few scalar instructions: the scalar unit is one per CU, shared by its four
+    // SIMDs, and this kernel keeps it about as busy as the vector ALUs.
+    const int stop = max(n_live - A.wait_threshold, 0);
+    const int leaf_weight = A.node_den - 1;
+    for (;;) {
+      bool leaf;
+      uint64_t ml;
       for (;;) {
         const bool inner = tv.cur < RF::LEAF;  // REF_EMPTY has the leaf bit set
+        leaf = (uint32_t)(tv.cur - RF::LEAF) < (RF::EMPTY - RF::LEAF);
         const uint64_t mi = __ballot(inner);
-        const uint64_t mt = __ballot(tv.cur != RF::EMPTY);
+        ml = __ballot(leaf);
         // leaves wait while at least 1/node_den of the travelling lanes still descend
-        if (mi == 0ull || A.node_den * __popcll(mi) < __popcll(mt)) break;
+        if (mi == 0ull || leaf_weight * __popcll(mi) < __popcll(ml)) break;
         if (inner) {
           node_step<R, CNT, WIDE>(sc, ray, tv, lds, t_min, cnt);
           if (CNT) cnt.v[CTR_ACTIVE]++;
@@ -1441,8 +1459,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
         if (CNT) cnt.v[CTR_STEPS]++;
         if (CNT) cnt.v[CTR_NODE_STEPS]++;
       }
-      const bool leaf = (uint32_t)(tv.cur - RF::LEAF) < (RF::EMPTY - RF::LEAF);
-      if (__ballot(leaf) != 0ull) {
+      if (ml != 0ull) {
         if (leaf) {
           leaf_test<R, CNT, WIDE, (FEAT & FEAT_TRIS) != 0u>(sc, ray, tv, tv.cur, t_min, cnt);
           tv.cur = trav_pop<R, WIDE>(tv, lds);
@@ -1450,10 +1467,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& A) {
         }
         if (CNT) cnt.v[CTR_STEPS]++;
       }
-      {
-        const int nt = __popcll(__ballot(tv.cur != RF::EMPTY)), nw = n_live - nt;
-        if (nw >= A.wait_threshold || nw * A.wait_ratio_den >= nt * A.wait_ratio_num) break;
-      }
+      if (__popcll(__ballot(tv.cur != RF::EMPTY)) <= stop) break;
     }
     if (CNT && lane == 0) cnt.v[CTR_CYC_TRAV] += (uint32_t)(__builtin_amdgcn_s_memtime() - ts2);
   }

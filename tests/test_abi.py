@@ -61,8 +61,8 @@ def test_options_need_no_device(ht):
     assert len(names) >= 20 and {"xcd_bands", "chunk", "wavefront", "bvh_optimise"} <= set(names), names
     # a value every option takes; then back to the defaults the library starts with
     defaults = {"wait_threshold": 0, "max_blocks_per_cu": 8, "max_waves_per_cu": 0, "flat_kernels": 1,
-                "bvh_optimise_max_nodes": 1 << 13, "block_threads": 0, "node_den": 2, "wait_ratio_num": 1000,
-                "wait_ratio_den": 1, "default_batch": 1024, "chunk": 0, "chunk_tail": 4, "gpu_bvh": 0,
+                "bvh_optimise_max_nodes": 1 << 13, "block_threads": 0, "node_den": 2,
+                "default_batch": 1024, "chunk": 0, "chunk_tail": 4, "gpu_bvh": 0,
                 "force_hbm_scene": 0, "wavefront": 0, "wavefront_paths": 1 << 24, "wavefront_refill": 32,
                 "bvh_optimise": 4, "timeline": 0, "xcd_bands": 1}
     assert set(names) == set(defaults), set(names) ^ set(defaults)

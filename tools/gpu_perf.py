@@ -12,14 +12,14 @@ ap.add_argument("scenes", nargs="*", default=["dragon", "random", "cornell"])
 ap.add_argument("--w", type=int, default=1920); ap.add_argument("--h", type=int, default=1080)
 ap.add_argument("--spp", type=int, default=64); ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--wait", type=int, nargs="*", default=[40]); ap.add_argument("--bpc", type=int, default=8)
-ap.add_argument("--counters", type=int, default=1); ap.add_argument("--chunk", type=int, default=8); ap.add_argument("--threads", type=int, default=0); ap.add_argument("--nden", type=int, default=2); ap.add_argument("--wnum", type=int, default=1000); ap.add_argument("--wden", type=int, default=1); ap.add_argument("--prec", type=int, default=0); ap.add_argument("--hbm", type=int, default=0); ap.add_argument("--ctail", type=int, default=4); ap.add_argument("--wavefront", type=int, default=0); ap.add_argument("--maxwaves", type=int, default=0); ap.add_argument("--gpubvh", type=int, default=0); ap.add_argument("--wfpaths", type=int, default=1 << 24); ap.add_argument("--wfrefill", type=int, default=32); ap.add_argument("--xcd", type=int, default=1)
+ap.add_argument("--counters", type=int, default=1); ap.add_argument("--chunk", type=int, default=8); ap.add_argument("--threads", type=int, default=0); ap.add_argument("--nden", type=int, default=2); ap.add_argument("--prec", type=int, default=0); ap.add_argument("--hbm", type=int, default=0); ap.add_argument("--ctail", type=int, default=4); ap.add_argument("--wavefront", type=int, default=0); ap.add_argument("--maxwaves", type=int, default=0); ap.add_argument("--gpubvh", type=int, default=0); ap.add_argument("--wfpaths", type=int, default=1 << 24); ap.add_argument("--wfrefill", type=int, default=32); ap.add_argument("--xcd", type=int, default=1)
 a = ap.parse_args()
 ht.set_option("force_hbm_scene", a.hbm); 
 try:
     ht.set_option("xcd_bands", a.xcd)
 except ht.HipTraceError:  # an older build of the library (A/B runs)
     pass
-ht.set_option("max_waves_per_cu", a.maxwaves); ht.set_option("gpu_bvh", a.gpubvh); ht.set_option("wavefront", a.wavefront); ht.set_option("wavefront_paths", a.wfpaths); ht.set_option("wavefront_refill", a.wfrefill); ht.set_option("chunk_tail", a.ctail); ht.set_option("max_blocks_per_cu", a.bpc); ht.set_option("chunk", a.chunk); ht.set_option("block_threads", a.threads); ht.set_option("node_den", a.nden); ht.set_option("wait_ratio_num", a.wnum); ht.set_option("wait_ratio_den", a.wden)
+ht.set_option("max_waves_per_cu", a.maxwaves); ht.set_option("gpu_bvh", a.gpubvh); ht.set_option("wavefront", a.wavefront); ht.set_option("wavefront_paths", a.wfpaths); ht.set_option("wavefront_refill", a.wfrefill); ht.set_option("chunk_tail", a.ctail); ht.set_option("max_blocks_per_cu", a.bpc); ht.set_option("chunk", a.chunk); ht.set_option("block_threads", a.threads); ht.set_option("node_den", a.nden)
 for name in a.scenes:
     if name.startswith("mesh:"):  # mesh:<n_lat>x<n_lon>: the procedural stand-in for miata.stl
         from raytracing_amd.meshgen import bumpy_ellipsoid
@@ -42,7 +42,7 @@ for name in a.scenes:
             ht.set_option("wait_threshold", wt)
             r = s.render(cam, W, H, a.spp, precision=a.prec, batch=a.batch, seed=1)
             st = r["stats"]
-            line = f"{name:8s} {W}x{H}x{a.spp} chunk={a.chunk} nden={a.nden} wratio={a.wnum}/{a.wden} wait={wt} kernel_s={st['seconds_kernel']:.4f} Msamples/s={st['samples']/st['seconds_kernel']/1e6:.1f} mean={r['rgb'].mean():.5f} cfg={st['block_threads']}x{st['blocks_per_cu']} lds={st['lds_bytes']} image={s.info()['lds_bytes_fp32']} depth={s.info()['bvh_depth']}"
+            line = f"{name:8s} {W}x{H}x{a.spp} chunk={a.chunk} nden={a.nden} wait={wt} kernel_s={st['seconds_kernel']:.4f} Msamples/s={st['samples']/st['seconds_kernel']/1e6:.1f} mean={r['rgb'].mean():.5f} cfg={st['block_threads']}x{st['blocks_per_cu']} lds={st['lds_bytes']} image={s.info()['lds_bytes_fp32']} depth={s.info()['bvh_depth']}"
             if a.counters:
                 r2 = s.render(cam, W, H, a.spp, precision=a.prec, batch=a.batch, seed=1, collect_counters=1)
                 c = r2["stats"]; ns = c["samples"]

@@ -18,8 +18,8 @@ MARKS = [
     ("      if (go) {\n        bounce++;", "RAY_SETUP+RAY_START"),
     ("    if (__ballot(state != ST_DONE) == 0ull) break;  // the queue is empty", "TRAVERSAL_HEAD"),
     ("      for (;;) {\n        const bool inner = tv.cur < RF::LEAF;", "NODE_STEPS_x2"),
-    ("      const bool leaf = (uint32_t)(tv.cur - RF::LEAF) < (RF::EMPTY - RF::LEAF);", "LEAF_STEP_PAIR"),
-    ("      {\n        const int nt = __popcll(__ballot(tv.cur != RF::EMPTY)), nw = n_live - nt;", "TRAVERSAL_POLICY"),
+    ("      if (ml != 0ull) {\n        if (leaf) {", "LEAF_STEP_PAIR"),
+    ("      if (__popcll(__ballot(tv.cur != RF::EMPTY)) <= stop) break;", "TRAVERSAL_POLICY"),
 ]
 for anchor, name in MARKS:
     assert anchor in src, anchor
