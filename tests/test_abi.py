@@ -58,7 +58,7 @@ def test_options_need_no_device(ht):
     text = open(os.path.join(ROOT, "include", "hiptrace.h")).read()
     doc = text[text.index("Process-wide tuning knobs"):text.index("int ht_set_option")]
     names = sorted(set(re.findall(r'"([a-z_0-9]+)"', doc)))
-    assert len(names) >= 20 and {"xcd_bands", "chunk", "wavefront", "bvh_optimise"} <= set(names), names
+    assert len(names) >= 18 and {"xcd_bands", "chunk", "wavefront", "bvh_optimise"} <= set(names), names
     # a value every option takes; then back to the defaults the library starts with
     defaults = {"wait_threshold": 0, "max_blocks_per_cu": 8, "max_waves_per_cu": 0, "flat_kernels": 1,
                 "bvh_optimise_max_nodes": 1 << 13, "block_threads": 0, "node_den": 2,
